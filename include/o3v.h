@@ -1,0 +1,182 @@
+/* o3v.h -- C ABI of libo3v_hip.so: the MI355X (gfx950) hot path of Open-o3-Video's generate loop.
+ *
+ * The reference (marinero4972/Open-o3-Video) is pure Python and has no FFI of its own: its boundary for this
+ * path is two Python call sites,
+ *   R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:581-582   model.generate(**prompt_inputs, generation_config)
+ *   R:eval/inference_example.py:81 / R:eval/models/model_vllm.py:103,117,125   llm.generate(inputs, sampling_params)
+ * and the arithmetic behind them lives in transformers (TF: = transformers 5.15.0,
+ * models/qwen2_5_vl/modeling_qwen2_5_vl.py).  This header is the boundary a maintainer binds instead
+ * (ctypes stub in INTEGRATION.md); each entry point names the reference code it replaces.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  All device buffers are caller-allocated, bf16 is a raw
+ * uint16 pattern, every call only ENQUEUES work on `stream` (no sync, no allocation, graph-capturable) and returns
+ * 0 or a negative O3V_ERR_* code; nothing throws.  Thread-safe for distinct streams.
+ */
+#ifndef O3V_H
+#define O3V_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* o3v_stream_t; /* hipStream_t */
+
+#define O3V_OK 0
+#define O3V_ERR_ARG (-1)    /* null pointer / negative size / inconsistent arguments */
+#define O3V_ERR_SHAPE (-2)  /* shape not supported by the kernels (alignment, head_dim, M > 8 for gemv ...) */
+#define O3V_ERR_LAUNCH (-3) /* HIP reported a launch failure */
+#define O3V_ERR_WORKSPACE (-4)
+
+#define O3V_EPI_NONE 0     /* out = bf16(acc + bias) */
+#define O3V_EPI_RESIDUAL 1 /* out = bf16(bf16(acc + bias) + res)                          TF:311-321, :733-755 */
+#define O3V_EPI_GELU 2     /* out = bf16(gelu_erf(bf16(acc + bias)))                       TF:141-145 merger */
+#define O3V_EPI_SWIGLU 3   /* out[:, j] = bf16(bf16(silu(gate_j)) * up_j); W rows packed by o3v 16-row interleave  TF:85-96,541-554 */
+
+int o3v_abi_version(void);
+
+/* ---- elementwise / layout (HBM-bound) ------------------------------------------------------------------- */
+/* Qwen2_5_VLRMSNorm.forward, TF:65-79 */
+int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, int cols, int ld_in, int ld_out, float eps,
+                o3v_stream_t stream);
+/* apply_rotary_pos_emb_vision, TF:160-171, in place on the q,k thirds of qkv[P,3*H*D]; cos/sin fp32 [P,D/2] */
+int o3v_vit_rope(void* qkv, const float* cosT, const float* sinT, int P, int H, int D, o3v_stream_t stream);
+/* Qwen2_5_VLRotaryEmbedding.forward + mrope section select, TF:525-538, :590-596; pos int32 [3,T] */
+int o3v_mrope_table(const int* pos, const float* inv_freq, const int* axis_of, void* cosT, void* sinT, int T, int D,
+                    o3v_stream_t stream);
+/* apply_multimodal_rotary_pos_emb + DynamicCache.update, TF:557-599, :652-664 */
+int o3v_qkv_rope_cache(const void* qkv, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache,
+                       int slot_base, int T, int tokens_per_row, int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
+                       int cs_off, o3v_stream_t stream);
+/* hidden_states[window_index] / [reverse_indices], TF:436-439, :464-466 */
+int o3v_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, o3v_stream_t stream);
+/* embed_tokens + masked_scatter of image embeds, TF:1206-1215 */
+int o3v_embed_scatter(const void* table, const void* vis, const int* src_row, void* out, int T, int hidden,
+                      o3v_stream_t stream);
+int o3v_embed_tokens(const void* table, const int* tok, void* out, int B, int hidden, o3v_stream_t stream);
+/* pixel_values.type(visual.dtype), TF:1090, with zero padding of the patch row to Kp */
+int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, o3v_stream_t stream);
+/* Qwen2VLImageProcessor rescale+normalize+patchify, TF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:152-233,
+ * on frames [T,3,H,W] (uint8 or f32 0..255) as R:vision_process.py:279-318 returns them */
+int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
+                 const float* std3, o3v_stream_t stream);
+
+/* ---- GEMMs ------------------------------------------------------------------------------------------------ */
+/* nn.Linear: out[M,N] = epi(A[M,K] . W[N,K]^T + bias); K % 64 == 0.  MFMA path (ViT, merger, prefill). */
+int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
+                  int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
+/* same contract for M <= 8: weight-streaming GEMV (decode). */
+int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int ldx,
+                  int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
+
+/* ---- attention ---------------------------------------------------------------------------------------------- */
+/* tiles: int32[n_tiles][8] = {q_row0, q_rows, k_row0, k_len, causal_off, k_lo, batch, 0}.
+ * ViT varlen attention (TF:248-287) and causal GQA prefill attention (TF:186-208, :602-689). */
+int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int Hq, int n_rep,
+                   int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
+                   float scale, o3v_stream_t stream);
+/* q_len == 1 attention against the cache [B,Hkv,Tmax,D]; part_o: f32[B*Hq*nsplit*D], part_ml: f32[B*Hq*nsplit*2] */
+int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
+                    const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
+                    o3v_stream_t stream);
+
+/* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
+/* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
+ * TF:generation/utils.py:2894-2929, TF:generation/logits_process.py:404-414 */
+int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
+                      const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
+                      int out_stride, o3v_stream_t stream);
+/* temperature + top-p + multinomial (TF:logits_process.py:301-303, :527-539; utils.py:2921-2923), counter-based RNG
+ * keyed by (seed, row_id[b], step) so a completion does not depend on which rank/batch slot produced it */
+int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* chosen_logprob,
+                     const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, float temperature,
+                     float top_p, uint64_t seed, const int* row_id, int step, int out_stride, float* scratch,
+                     o3v_stream_t stream);
+int o3v_mark_seen(const int* ids, void* seen, int B, int S, int V, o3v_stream_t stream);
+/* _get_per_token_logps, R:grpo_trainer.py:371-384: out[r] = log_softmax(logits[r])[target[r]] */
+int o3v_logprob_gather(const void* logits, const int* target, float* out, int R, int V, int ldl, o3v_stream_t stream);
+
+/* ---- model-level engine (layer loops in C++, no Python per kernel) ------------------------------------------- */
+typedef struct {
+    const void *norm1, *norm2;     /* [hid] */
+    const void *qkv_w, *qkv_b;     /* [3hid,hid], [3hid] */
+    const void *proj_w, *proj_b;   /* [hid,hid], [hid] */
+    const void *gu_w, *gu_b;       /* packed gate/up [2*ipad,hid], [2*ipad] (16-row interleave, zero pad rows) */
+    const void *down_w, *down_b;   /* [hid,ipad] (zero pad cols), [hid] */
+} o3v_vit_block_w;
+
+typedef struct {
+    int depth, hidden, heads, inter_pad, out_hidden, patch_k_pad, merge_unit;
+    uint64_t fullatt_mask;         /* bit i set: block i attends over whole frames (TF:448-454) */
+    const void* patch_w;           /* [hidden, patch_k_pad] (Conv3d weight flattened, zero pad cols)  TF:99-122 */
+    const o3v_vit_block_w* blocks; /* [depth] */
+    const void *ln_q, *m0_w, *m0_b, *m2_w, *m2_b; /* merger TF:137-150 */
+} o3v_vit_desc;
+
+typedef struct {
+    const void *ln1, *ln2;       /* [H] */
+    const void *qkv_w, *qkv_b;   /* fused q|k|v [(Hq+2Hkv)*D, H] */
+    const void* o_w;             /* [H, Hq*D] */
+    const void* gu_w;            /* packed gate/up [2*I, H] */
+    const void* down_w;          /* [H, I] */
+} o3v_llm_layer_w;
+
+typedef struct {
+    int hidden, layers, heads, kv_heads, head_dim, inter, vocab;
+    float rms_eps;
+    const void* embed;           /* [vocab, H] */
+    const o3v_llm_layer_w* layer;/* [layers] */
+    const void* final_norm;      /* [H] */
+    const void* lm_head;         /* [vocab, H] (== embed when tied) */
+} o3v_llm_desc;
+
+size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P);
+/* Qwen2_5_VisionTransformerPretrainedModel.forward, TF:408-471.  pixels: bf16 [P, patch_k_pad]; win_idx/rev_idx
+ * int32 [P/merge_unit]; cos/sin f32 [P, head_dim/2] in window order; out bf16 [P/merge_unit, out_hidden]. */
+int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P, const int* win_idx, const int* rev_idx,
+                    const float* cosT, const float* sinT, const int* tiles_win, int n_tiles_win, const int* tiles_full,
+                    int n_tiles_full, void* workspace, size_t ws_bytes, void* out, o3v_stream_t stream);
+
+size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
+/* Qwen2_5_VLTextModel.forward over the prompt, TF:790-872: x bf16 [B*S,H] holds inputs_embeds on entry and the
+ * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D]. */
+int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
+                    void* kcache, void* vcache, int B, int S, int Tmax, void* workspace, size_t ws_bytes,
+                    o3v_stream_t stream);
+/* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
+int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
+                 o3v_stream_t stream);
+
+typedef struct {
+    int B, S, Tmax, Tnew;        /* rows, prompt slots already in the cache, cache capacity, decode table length */
+    int nsplit;                  /* context splits of the decode attention */
+    int pad_id, n_eos;
+    int do_sample;               /* 0 greedy, 1 temperature/top-p multinomial */
+    float rep_penalty, temperature, top_p;
+    uint64_t seed;
+    void *x;                     /* bf16 [B,H] scratch: residual stream of the current token */
+    void *kcache, *vcache;       /* [layers][B][Hkv][Tmax][D] */
+    const void *cosT, *sinT;     /* bf16 [B,Tnew,D]: M-RoPE table of the decode positions (TF:1164-1174) */
+    void *logits;                /* bf16 [B,vocab]; holds the logits to sample from on entry */
+    void *seen;                  /* u8 [B,vocab] */
+    int *cur_tok, *finished;     /* [B] */
+    int *out_ids;                /* [B,Tnew] */
+    float *margins;              /* [B,Tnew] top1-top2 (greedy) or chosen log-prob (sampling); may be NULL */
+    const int *eos_ids;          /* [n_eos] */
+    const int *k_lo;             /* [B] left-pad counts or NULL */
+    const int *row_id;           /* [B] global completion index for the RNG or NULL */
+    float *part_o, *part_ml;     /* decode-attention split buffers */
+    float *sample_scratch;       /* f32 [B,vocab] (sampling only) */
+    void *workspace; size_t ws_bytes;
+} o3v_decode_state;
+
+/* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from
+ * st->logits, then (unless it is the globally last step) run one decode forward to refill st->logits. */
+int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st, int step0, int n_steps, int skip_last_forward,
+                   o3v_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3V_H */

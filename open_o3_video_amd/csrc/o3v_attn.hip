@@ -1,0 +1,391 @@
+// Attention kernels of the Qwen2.5-VL generate path on gfx950 (MI355X).
+//
+//   o3v_attn_tiles  : flash-style attention over a list of 64-row query tiles.  Serves the ViT
+//                     (non-causal, ragged segments from cu_seqlens: windows <= 64 patches and whole
+//                     frames, TF:modeling_qwen2_5_vl.py:248-287) and the LLM prefill (causal, GQA, left
+//                     padding, K/V read from the cache, TF:602-689).
+//   o3v_attn_decode : one query token per sequence against the whole cache (HBM-bound KV read), split
+//                     over the context; o3v_attn_decode_combine merges the splits.
+//
+// Flash kernel layout ("swapped QK^T", so nothing ever crosses lanes between the two MFMA chains):
+//   S^T[key][q]  = K_tile . Q^T   A = K rows from LDS (ds_read_b128), B = Q rows held in VGPRs
+//   accumulator: lane (q = lane&15, g = lane>>4) holds keys 16*kb + 4g + r  -> softmax state (m, l) of
+//   query q lives in the lane; the row max needs two shuffles (xor 16, 32), the row sum none.
+//   O^T[d][q]   += V^T . P^T      B = P^T straight from the S accumulators (cvt to bf16, k-slot order
+//   permuted consistently), A = V^T fetched with ds_read_b64_tr_b16 from the row-major V tile.
+// fp32 scores/softmax/accumulators; P is rounded to bf16 before P.V as the reference's bf16 attention does.
+#include "o3v_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct TileDesc {  // 8 ints, built on the host (open_o3_video_amd/indexing.py)
+    int q_row0;      // first query token (row of Q / O)
+    int q_rows;      // valid rows in this tile (1..64)
+    int k_row0;      // first key token of the segment inside the (batch-offset) K / V arrays
+    int k_len;       // keys in the segment / cache length
+    int causal_off;  // >= 0: key j allowed iff j <= causal_off + row_in_tile ; < 0: no causal mask
+    int k_lo;        // first valid key (left padding)
+    int batch;       // batch row (selects the K/V batch stride)
+    int pad_;
+};
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DPAD = (D + 31) / 32 * 32;       // QK^T k-steps of 32
+    static constexpr int KS = DPAD / 32;
+    static constexpr int DB = D / 16;                      // 16-wide output d blocks
+    // row strides (bytes): K rows read by ds_read_b128 want stride/16 odd, V rows read by
+    // ds_read_b64_tr_b16 (8 rows x 32 B per half-wave) want stride/32 odd -> conflict-free.
+    static constexpr int KSTRIDE = DPAD * 2 + 16;
+    static constexpr int VSTRIDE = ((D * 2 / 32) % 2 == 1) ? D * 2 : D * 2 + 32;
+    static constexpr int K_BYTES = 64 * KSTRIDE;
+    static constexpr int V_BYTES = 64 * VSTRIDE;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                         const TileDesc* __restrict__ tiles, long q_ts, long k_ts,
+                                                         long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
+                                                         int n_rep, float scale_log2e) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + C::K_BYTES;
+
+    const TileDesc td = tiles[blockIdx.x];
+    const int h = blockIdx.y, hk = h / n_rep;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][ks*32 + 8*fg .. +7]
+    const int qrow_in = wave * 16 + fr;
+    const int qrow_ld = td.q_row0 + (qrow_in < td.q_rows ? qrow_in : td.q_rows - 1);
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        const int d0 = ks * 32 + fg * 8;
+        if (d0 < D)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qrow_ld * q_ts + (size_t)h * D + d0);
+        else
+            qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4 o[C::DB];
+#pragma unroll
+    for (int i = 0; i < C::DB; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* Kb = K + (size_t)td.batch * k_bs + (size_t)hk * k_hs + (size_t)td.k_row0 * k_ts;
+    const bf16_t* Vb = V + (size_t)td.batch * v_bs + (size_t)hk * v_hs + (size_t)td.k_row0 * v_ts;
+
+    int k_end = td.k_len;
+    if (td.causal_off >= 0) {
+        const int lim = td.causal_off + td.q_rows;  // exclusive
+        k_end = lim < k_end ? lim : k_end;
+    }
+    const int kt_lo = td.k_lo >> 6;
+    const int kt_hi = (k_end + 63) >> 6;
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K (zero padded to DPAD) and V tiles through registers
+        {
+            constexpr int CPR = C::DPAD / 8;
+            for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
+                const int row = c / CPR, ch = c % CPR;
+                int kr = kt * 64 + row;
+                kr = kr < td.k_len ? kr : td.k_len - 1;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ch * 8 < D) v = *reinterpret_cast<const uint4*>(Kb + (size_t)kr * k_ts + ch * 8);
+                *reinterpret_cast<uint4*>(Kl + row * C::KSTRIDE + ch * 16) = v;
+            }
+            constexpr int VPR = D / 8;
+            for (int c = threadIdx.x; c < 64 * VPR; c += 256) {
+                const int row = c / VPR, ch = c % VPR;
+                int kr = kt * 64 + row;
+                kr = kr < td.k_len ? kr : td.k_len - 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(Vb + (size_t)kr * v_ts + ch * 8);
+                *reinterpret_cast<uint4*>(Vl + row * C::VSTRIDE + ch * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : 4 key blocks of 16
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const bf16x8 kf =
+                    *reinterpret_cast<const bf16x8*>(Kl + (kb * 16 + fr) * C::KSTRIDE + (ks * 32 + fg * 8) * 2);
+                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax (query = fr, this lane's keys = kt*64 + kb*16 + 4*fg + r)
+        float mx = -1e30f;
+        bool ok[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kt * 64 + kb * 16 + fg * 4 + r;
+                bool v = (j < td.k_len) && (j >= td.k_lo);
+                if (td.causal_off >= 0) v = v && (j <= td.causal_off + qrow_in);
+                ok[kb][r] = v;
+                const float sv = v ? s[kb][r] * scale_log2e : -1e30f;
+                s[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pb[2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = ok[kb][r] ? __builtin_amdgcn_exp2f(s[kb][r] - m_new) : 0.f;
+                psum += p;
+                pb[kb >> 1][(kb & 1) * 4 + r] = (short)f2bf(p);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < C::DB; ++i) o[i] *= alpha;
+
+        // ---- O^T += V^T . P^T.  k-slot j of lane group fg: j<4 -> key 32kk + 4fg + j ; j>=4 -> key 32kk + 16 + 4fg + (j-4)
+        const int tq = fr >> 2, tp = fr & 3;  // tr-read: lane 4q+p of the 16-lane group addresses row q, cols 4p..4p+3
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const char* r0 = Vl + (kk * 32 + fg * 4 + tq) * C::VSTRIDE + tp * 8;
+            const char* r1 = r0 + 16 * C::VSTRIDE;
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db) {
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + db * 32));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + db * 32));
+                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[kk], o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finalize: l over the 4 lane groups, O[q][d = db*16 + 4fg + r]
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow_in < td.q_rows) {
+        bf16_t* orow = O + (size_t)(td.q_row0 + qrow_in) * o_ts + (size_t)h * D + fg * 4;
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+            u32x2 pk;
+            pk[0] = pack_bf2(o[db][0] * inv, o[db][1] * inv);
+            pk[1] = pack_bf2(o[db][2] * inv, o[db][3] * inv);
+            *reinterpret_cast<u32x2*>(orow + db * 16) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode attention.  grid (splits, Hkv, B), 4 waves.  A wave-iteration covers KPW = 64/(D/8) keys:
+// lane (slot = lane / LPK, part = lane % LPK) loads 16 B of K and of V of key slot `slot`; the n_rep
+// query heads of the kv head share every K/V byte (GQA).  Each (wave, slot) is an independent online
+// softmax stream; streams are merged at the end, splits by o3v_attn_decode_combine.
+// ------------------------------------------------------------------------------------------------
+constexpr int NREP_MAX = 8;
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                          const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                          float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
+                                                          int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
+                                                          float scale_log2e) {
+    constexpr int LPK = D / 8, KPW = 64 / LPK;
+    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane / LPK, part = lane % LPK;
+    const int k_lo = k_lo_arr ? k_lo_arr[b] : 0;
+
+    int chunk = (ctx + nsplit - 1) / nsplit;
+    chunk = (chunk + 4 * KPW - 1) / (4 * KPW) * (4 * KPW);
+    const int k0 = split * chunk;
+    int k1 = k0 + chunk;
+    k1 = k1 < ctx ? k1 : ctx;
+
+    float q[NREP_MAX][8];
+#pragma unroll
+    for (int r = 0; r < NREP_MAX; ++r) {
+        const int hh = hk * n_rep + (r < n_rep ? r : n_rep - 1);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Q + ((size_t)b * Hq + hh) * D + part * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q[r][2 * j] = bf_lo(v[j]) * scale_log2e;
+            q[r][2 * j + 1] = bf_hi(v[j]) * scale_log2e;
+        }
+    }
+    float m[NREP_MAX], l[NREP_MAX], o[NREP_MAX][8];
+#pragma unroll
+    for (int r = 0; r < NREP_MAX; ++r) {
+        m[r] = -1e30f;
+        l[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[r][j] = 0.f;
+    }
+    const bf16_t* Kb = Kc + (size_t)b * k_bs + (size_t)hk * k_hs;
+    const bf16_t* Vb = Vc + (size_t)b * k_bs + (size_t)hk * k_hs;
+
+    for (int kbase = k0 + wave * KPW; kbase < k1; kbase += 4 * KPW) {
+        const int key = kbase + slot;
+        const bool valid = key < k1 && key >= k_lo;
+        const int kl = key < ctx ? key : ctx - 1;
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)kl * D + part * 8);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)kl * D + part * 8);
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kf[2 * j] = bf_lo(kv[j]);
+            kf[2 * j + 1] = bf_hi(kv[j]);
+            vf[2 * j] = bf_lo(vv[j]);
+            vf[2 * j + 1] = bf_hi(vv[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < NREP_MAX; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf(q[r][j], kf[j], s);
+#pragma unroll
+            for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            s = valid ? s : -1e30f;
+            const float mn = fmaxf(m[r], s);
+            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+            float p = valid ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
+            p = bf2f(f2bf(p));  // the reference rounds the probabilities to bf16 before P.V
+            m[r] = mn;
+            l[r] = l[r] * alpha + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
+        }
+    }
+    // ---- merge the KPW slot streams of this wave (lanes with equal `part`)
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < NREP_MAX; ++r) {
+            const float mo = __shfl_xor(m[r], off, 64), lo = __shfl_xor(l[r], off, 64);
+            const float mn = fmaxf(m[r], mo);
+            const float a = __builtin_amdgcn_exp2f(m[r] - mn), bsc = __builtin_amdgcn_exp2f(mo - mn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[r][j] = o[r][j] * a + __shfl_xor(o[r][j], off, 64) * bsc;
+            l[r] = l[r] * a + lo * bsc;
+            m[r] = mn;
+        }
+    }
+    // ---- merge the 4 waves through LDS
+    __shared__ float sm[4][NREP_MAX], sl[4][NREP_MAX], so[4][NREP_MAX][D];
+    if (slot == 0) {
+#pragma unroll
+        for (int r = 0; r < NREP_MAX; ++r) {
+            if (part == 0) {
+                sm[wave][r] = m[r];
+                sl[wave][r] = l[r];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) so[wave][r][part * 8 + j] = o[r][j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rep * D; i += 256) {
+        const int r = i / D, d = i % D;
+        float mn = fmaxf(fmaxf(sm[0][r], sm[1][r]), fmaxf(sm[2][r], sm[3][r]));
+        float acc = 0.f, lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __builtin_amdgcn_exp2f(sm[w][r] - mn);
+            acc += so[w][r][d] * sc;
+            lt += sl[w][r] * sc;
+        }
+        const size_t idx = (((size_t)b * Hq + hk * n_rep + r) * nsplit + split);
+        part_o[idx * D + d] = acc;
+        if (d == 0) {
+            part_ml[idx * 2] = mn;
+            part_ml[idx * 2 + 1] = lt;
+        }
+    }
+}
+
+template <int D>
+__global__ void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                           bf16_t* __restrict__ out, int nsplit) {
+    const int bh = blockIdx.x;  // b*Hq + h
+    const int d = threadIdx.x;
+    if (d >= D) return;
+    float mn = -1e30f;
+    for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, part_ml[((size_t)bh * nsplit + s) * 2]);
+    float acc = 0.f, lt = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t idx = (size_t)bh * nsplit + s;
+        const float sc = __builtin_amdgcn_exp2f(part_ml[idx * 2] - mn);
+        acc += part_o[idx * D + d] * sc;
+        lt += part_ml[idx * 2 + 1] * sc;
+    }
+    out[(size_t)bh * D + d] = f2bf(lt > 0.f ? acc / lt : 0.f);
+}
+
+}  // namespace
+
+extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int Hq,
+                              int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs,
+                              long v_bs, long o_ts, float scale, hipStream_t stream) {
+    if (!Q || !K || !V || !O || !tiles || n_tiles < 0 || Hq <= 0 || n_rep <= 0 || (Hq % n_rep)) return O3V_ERR_ARG;
+    if ((q_ts & 7) || (k_ts & 7) || (v_ts & 7) || (k_hs & 7) || (v_hs & 7) || (o_ts & 3)) return O3V_ERR_SHAPE;
+    if (n_tiles == 0) return O3V_OK;
+    const float sl2 = scale * 1.4426950408889634f;
+    dim3 grid(n_tiles, Hq), block(256);
+#define O3V_AT(DD)                                                                                                    \
+    hipLaunchKernelGGL((attn_tiles_kernel<DD>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
+                       (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, (const TileDesc*)tiles, q_ts, \
+                       k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2)
+    switch (D) {
+        case 32: O3V_AT(32); break;
+        case 64: O3V_AT(64); break;
+        case 80: O3V_AT(80); break;
+        case 128: O3V_AT(128); break;
+        default: return O3V_ERR_SHAPE;
+    }
+#undef O3V_AT
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
+                               const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
+                               hipStream_t stream) {
+    if (!Q || !Kc || !Vc || !out || !part_o || !part_ml || B < 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || ctx <= 0 ||
+        ctx > Tmax || nsplit <= 0)
+        return O3V_ERR_ARG;
+    const int n_rep = Hq / Hkv;
+    if (n_rep > NREP_MAX) return O3V_ERR_SHAPE;
+    if (B == 0) return O3V_OK;
+    const float sl2 = scale * 1.4426950408889634f;
+    const long k_hs = (long)Tmax * D, k_bs = (long)Hkv * Tmax * D;
+    dim3 grid(nsplit, Hkv, B), block(256);
+#define O3V_AD(DD)                                                                                                     \
+    hipLaunchKernelGGL((attn_decode_kernel<DD>), grid, block, 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc,           \
+                       (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2);                \
+    hipLaunchKernelGGL((attn_decode_combine_kernel<DD>), dim3(B* Hq), dim3(DD < 64 ? 64 : DD), 0, stream, part_o,      \
+                       part_ml, (bf16_t*)out, nsplit)
+    switch (D) {
+        case 32: O3V_AD(32); break;
+        case 64: O3V_AD(64); break;
+        case 128: O3V_AD(128); break;
+        default: return O3V_ERR_SHAPE;
+    }
+#undef O3V_AD
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}

@@ -1,0 +1,565 @@
+// HBM-bound elementwise / normalisation / layout kernels of the Qwen2.5-VL generate path (gfx950).
+// All of them move 16 B per lane per access (8 bf16) and keep every intermediate in fp32 with the
+// reference's bf16 rounding points.  Reference arithmetic: transformers 5.15.0
+// models/qwen2_5_vl/modeling_qwen2_5_vl.py ("TF:" below) as called by the Open-o3-Video trainer
+// (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:581-586) -- see include/o3v.h for the boundary.
+#include "o3v_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (TF:65-79): out = w * bf16(x * rsqrt(mean(x^2)+eps)); one wave per row, row held in VGPRs.
+// ------------------------------------------------------------------------------------------------
+template <int MAXCH>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ out, int rows, int cols, int ld_in,
+                                                      int ld_out, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;  // 16-byte chunks per row
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * ld_in);
+    uint4 v[MAXCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = xr[c];
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = bf_lo(p[j]), b = bf_hi(p[j]);
+                ss = fmaf(a, a, ss);
+                ss = fmaf(b, b, ss);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)cols + eps);
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    uint4* orow = reinterpret_cast<uint4*>(out + (size_t)row * ld_out);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + i * 64;
+        if (c < nch) {
+            uint4 wv = wr[c];
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv);
+            uint4 o;
+            uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = rbf(bf_lo(p[j]) * rstd), b = rbf(bf_hi(p[j]) * rstd);
+                po[j] = pack_bf2(bf_lo(q[j]) * a, bf_hi(q[j]) * b);
+            }
+            orow[c] = o;
+        }
+    }
+}
+
+extern "C" int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, int cols, int ld_in, int ld_out,
+                           float eps, hipStream_t stream) {
+    if (!x || !w || !out || rows < 0 || cols <= 0 || (cols & 7) || (ld_in & 7) || (ld_out & 7)) return O3V_ERR_ARG;
+    if (rows == 0) return O3V_OK;
+    if (cols > 16 * 512) return O3V_ERR_SHAPE;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (cols <= 4 * 512)
+        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+                           rows, cols, ld_in, ld_out, eps);
+    else if (cols <= 8 * 512)
+        hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+                           rows, cols, ld_in, ld_out, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+                           rows, cols, ld_in, ld_out, eps);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT 2-D RoPE in place on the q and k thirds of qkv [P, 3*H*D] (TF:160-171): fp32,
+// q*cos + rotate_half(q)*sin with separately rounded products, one cast back to bf16.
+// cos/sin: fp32 [P, D/2] (the table is cat(rot, rot), so column d and d+D/2 share an entry).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cosT,
+                                                       const float* __restrict__ sinT, int P, int H, int D) {
+    const int half = D >> 1, cpr = half >> 3;  // 8-wide chunks per half head
+    const long total = (long)P * 2 * H * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cpr);
+        long r = i / cpr;
+        int h = (int)(r % H);
+        r /= H;
+        int which = (int)(r & 1);  // 0 = q, 1 = k
+        int p = (int)(r >> 1);
+        bf16_t* base = qkv + (size_t)p * 3 * H * D + (size_t)which * H * D + (size_t)h * D + c * 8;
+        uint4 lo = *reinterpret_cast<const uint4*>(base);
+        uint4 hi = *reinterpret_cast<const uint4*>(base + half);
+        const float* cr = cosT + (size_t)p * half + c * 8;
+        const float* sr = sinT + (size_t)p * half + c * 8;
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&lo);
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&hi);
+        uint4 ol, oh;
+        uint32_t* pol = reinterpret_cast<uint32_t*>(&ol);
+        uint32_t* poh = reinterpret_cast<uint32_t*>(&oh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a0 = bf_lo(pl[j]), a1 = bf_hi(pl[j]);  // x1 (first half)
+            float b0 = bf_lo(ph[j]), b1 = bf_hi(ph[j]);  // x2 (second half)
+            float c0 = cr[2 * j], c1 = cr[2 * j + 1], s0 = sr[2 * j], s1 = sr[2 * j + 1];
+            // first half: x1*cos + (-x2)*sin ; second half: x2*cos + x1*sin
+            float l0 = __fadd_rn(__fmul_rn(a0, c0), __fmul_rn(-b0, s0));
+            float l1 = __fadd_rn(__fmul_rn(a1, c1), __fmul_rn(-b1, s1));
+            float h0 = __fadd_rn(__fmul_rn(b0, c0), __fmul_rn(a0, s0));
+            float h1 = __fadd_rn(__fmul_rn(b1, c1), __fmul_rn(a1, s1));
+            pol[j] = pack_bf2(l0, l1);
+            poh[j] = pack_bf2(h0, h1);
+        }
+        *reinterpret_cast<uint4*>(base) = ol;
+        *reinterpret_cast<uint4*>(base + half) = oh;
+    }
+}
+
+extern "C" int o3v_vit_rope(void* qkv, const float* cosT, const float* sinT, int P, int H, int D, hipStream_t stream) {
+    if (!qkv || !cosT || !sinT || P < 0 || H <= 0 || D <= 0 || (D & 15)) return O3V_ERR_ARG;
+    if (P == 0) return O3V_OK;
+    long total = (long)P * 2 * H * (D >> 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vit_rope_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)qkv, cosT, sinT, P, H, D);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-RoPE cos/sin table (TF:525-538 + section select TF:590-596): pos int32 [3, T], inv_freq fp32
+// [D/2] (computed on the host exactly as torch does), axis_of[D/2] in {0,1,2} -> cos,sin bf16 [T, D].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mrope_table_kernel(const int* __restrict__ pos, const float* __restrict__ inv_freq,
+                                                          const int* __restrict__ axis_of, bf16_t* __restrict__ cosT,
+                                                          bf16_t* __restrict__ sinT, int T, int D) {
+    const int half = D >> 1;
+    long total = (long)T * half;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int d = (int)(i % half);
+        int t = (int)(i / half);
+        float f = __fmul_rn(inv_freq[d], (float)pos[(size_t)axis_of[d] * T + t]);
+        bf16_t c = f2bf(cosf(f)), s = f2bf(sinf(f));
+        cosT[(size_t)t * D + d] = c;
+        cosT[(size_t)t * D + d + half] = c;
+        sinT[(size_t)t * D + d] = s;
+        sinT[(size_t)t * D + d + half] = s;
+    }
+}
+
+extern "C" int o3v_mrope_table(const int* pos, const float* inv_freq, const int* axis_of, void* cosT, void* sinT, int T,
+                               int D, hipStream_t stream) {
+    if (!pos || !inv_freq || !axis_of || !cosT || !sinT || T < 0 || D <= 0 || (D & 1)) return O3V_ERR_ARG;
+    if (T == 0) return O3V_OK;
+    long total = (long)T * (D >> 1);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mrope_table_kernel, dim3(blocks), dim3(256), 0, stream, pos, inv_freq, axis_of, (bf16_t*)cosT,
+                       (bf16_t*)sinT, T, D);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM: split qkv [T, (Hq+2Hkv)*D], apply M-RoPE in bf16 (TF:598-599: bf16(bf16(q*cos)+bf16(rh*sin))),
+// write q [T,Hq,D] and append k,v to the cache [B,Hkv,Tmax,D] at slot_base + (t % tokens_per_row).
+// token t belongs to batch row b = t / tokens_per_row; its cos/sin row is
+// b*cs_stride_row + cs_off + (t % tokens_per_row)  (prefill: the [B*S,D] table; decode: step `cs_off`
+// of the per-sequence [B,Tnew,D] table).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qkv_rope_cache_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cosT,
+                                                             const bf16_t* __restrict__ sinT, bf16_t* __restrict__ qout,
+                                                             bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                             int slot_base, int T, int tokens_per_row,
+                                                             int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
+                                                             int cs_off) {
+    const int half = D >> 1, cpr = half >> 3;
+    const int HT = Hq + 2 * Hkv;
+    const long total = (long)T * HT * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cpr);
+        long r = i / cpr;
+        int h = (int)(r % HT);
+        int t = (int)(r / HT);
+        int b = t / tokens_per_row;
+        const int tin = t - b * tokens_per_row;
+        const int slot = slot_base + tin;
+        const bf16_t* src = qkv + (size_t)t * HT * D + (size_t)h * D + c * 8;
+        uint4 lo = *reinterpret_cast<const uint4*>(src);
+        uint4 hi = *reinterpret_cast<const uint4*>(src + half);
+        bf16_t* dst;
+        if (h < Hq) {
+            dst = qout + ((size_t)t * Hq + h) * D + c * 8;
+        } else if (h < Hq + Hkv) {
+            dst = kc + (((size_t)b * Hkv + (h - Hq)) * Tmax + slot) * D + c * 8;
+        } else {
+            dst = vc + (((size_t)b * Hkv + (h - Hq - Hkv)) * Tmax + slot) * D + c * 8;
+            *reinterpret_cast<uint4*>(dst) = lo;
+            *reinterpret_cast<uint4*>(dst + half) = hi;
+            continue;
+        }
+        // cos/sin row: row-major [rows, D]; both halves hold the same value so read the first half only
+        size_t csr = (size_t)(b * cs_stride_row + cs_off + tin) * D + c * 8;
+        uint4 cv = *reinterpret_cast<const uint4*>(cosT + csr);
+        uint4 sv = *reinterpret_cast<const uint4*>(sinT + csr);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&lo);
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&hi);
+        const uint32_t* pc = reinterpret_cast<const uint32_t*>(&cv);
+        const uint32_t* ps = reinterpret_cast<const uint32_t*>(&sv);
+        uint4 ol, oh;
+        uint32_t* pol = reinterpret_cast<uint32_t*>(&ol);
+        uint32_t* poh = reinterpret_cast<uint32_t*>(&oh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a0 = bf_lo(pl[j]), a1 = bf_hi(pl[j]), b0 = bf_lo(ph[j]), b1 = bf_hi(ph[j]);
+            float c0 = bf_lo(pc[j]), c1 = bf_hi(pc[j]), s0 = bf_lo(ps[j]), s1 = bf_hi(ps[j]);
+            float l0 = rbf(__fadd_rn(rbf(__fmul_rn(a0, c0)), rbf(__fmul_rn(-b0, s0))));
+            float l1 = rbf(__fadd_rn(rbf(__fmul_rn(a1, c1)), rbf(__fmul_rn(-b1, s1))));
+            float h0 = rbf(__fadd_rn(rbf(__fmul_rn(b0, c0)), rbf(__fmul_rn(a0, s0))));
+            float h1 = rbf(__fadd_rn(rbf(__fmul_rn(b1, c1)), rbf(__fmul_rn(a1, s1))));
+            pol[j] = pack_bf2(l0, l1);
+            poh[j] = pack_bf2(h0, h1);
+        }
+        *reinterpret_cast<uint4*>(dst) = ol;
+        *reinterpret_cast<uint4*>(dst + half) = oh;
+    }
+}
+
+extern "C" int o3v_qkv_rope_cache(const void* qkv, const void* cosT, const void* sinT, void* qout, void* kcache,
+                                  void* vcache, int slot_base, int T, int tokens_per_row, int Hq, int Hkv, int D,
+                                  int Tmax, int cs_stride_row, int cs_off, hipStream_t stream) {
+    if (!qkv || !cosT || !sinT || !qout || !kcache || !vcache || slot_base < 0 || T < 0 || tokens_per_row <= 0 || (D & 15) ||
+        slot_base + tokens_per_row > Tmax)
+        return O3V_ERR_ARG;
+    if (T == 0) return O3V_OK;
+    long total = (long)T * (Hq + 2 * Hkv) * (D >> 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(qkv_rope_cache_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
+                       (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache, slot_base, T, tokens_per_row, Hq,
+                       Hkv, D, Tmax, cs_stride_row, cs_off);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row gather: dst[i,:] = src[idx[i],:], rows of row_bytes (multiple of 16).  Used for the ViT window
+// permutation at 4-token granularity and its inverse (TF:436-439, :464-466).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ idx,
+                                                          uint4* __restrict__ dst, int rows, int chunks) {
+    long total = (long)rows * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % chunks);
+        int r = (int)(i / chunks);
+        dst[(size_t)r * chunks + c] = src[(size_t)idx[r] * chunks + c];
+    }
+}
+
+extern "C" int o3v_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, hipStream_t stream) {
+    if (!src || !idx || !dst || rows < 0 || row_bytes <= 0 || (row_bytes & 15)) return O3V_ERR_ARG;
+    if (rows == 0) return O3V_OK;
+    long total = (long)rows * (row_bytes >> 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, idx, (uint4*)dst, rows,
+                       row_bytes >> 4);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token embedding gather + masked scatter of the merged visual tokens (TF:1206-1215):
+// src_row[t] >= 0 -> embed_table[src_row[t]] ; src_row[t] < 0 -> vis[-src_row[t]-1].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const uint4* __restrict__ table, const uint4* __restrict__ vis,
+                                                            const int* __restrict__ src_row, uint4* __restrict__ out,
+                                                            int T, int chunks) {
+    long total = (long)T * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % chunks);
+        int t = (int)(i / chunks);
+        int r = src_row[t];
+        out[(size_t)t * chunks + c] = (r >= 0) ? table[(size_t)r * chunks + c] : vis[(size_t)(-r - 1) * chunks + c];
+    }
+}
+
+extern "C" int o3v_embed_scatter(const void* table, const void* vis, const int* src_row, void* out, int T, int hidden,
+                                 hipStream_t stream) {
+    if (!table || !src_row || !out || T < 0 || hidden <= 0 || (hidden & 7)) return O3V_ERR_ARG;
+    if (T == 0) return O3V_OK;
+    long total = (long)T * (hidden >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, (const uint4*)vis,
+                       src_row, (uint4*)out, T, hidden >> 3);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pixel_values f32 [P, K0] (already normalised by the HF processor) -> bf16 [P, Kp] zero padded
+// (TF:1090 `pixel_values.type(self.visual.dtype)`; the pad columns meet zero weight columns).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int P,
+                                                       int K0, int Kp) {
+    const int cpr = Kp >> 3;
+    long total = (long)P * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cpr);
+        int p = (int)(i / cpr);
+        const float* s = src + (size_t)p * K0 + c * 8;
+        uint4 o;
+        uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = c * 8 + 2 * j;
+            float a = (k < K0) ? s[2 * j] : 0.f;
+            float b = (k + 1 < K0) ? s[2 * j + 1] : 0.f;
+            po[j] = pack_bf2(a, b);
+        }
+        *reinterpret_cast<uint4*>(dst + (size_t)p * Kp + c * 8) = o;
+    }
+}
+
+extern "C" int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, hipStream_t stream) {
+    if (!src || !dst || P < 0 || K0 <= 0 || Kp < K0 || (Kp & 7)) return O3V_ERR_ARG;
+    if (P == 0) return O3V_OK;
+    long total = (long)P * (Kp >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, P, K0, Kp);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused frame pipeline: frames [T,3,H,W] (u8 or f32, values 0..255) -> rescale 1/255 (in double, as
+// TF:image_transforms.py:118 does), CLIP normalise (fp32), patchify to merge-block-major rows with the
+// temporal slice duplicated (TF:image_processing_pil_qwen2_vl.py:152-187), cast bf16, zero pad to Kp.
+// ------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ frames, bf16_t* __restrict__ dst, int T,
+                                                       int H, int W, int Kp, float m0, float m1, float m2, float s0,
+                                                       float s1, float s2) {
+    const int PS = 14, gh = H / PS, gw = W / PS, ppf = gh * gw, gwm = gw >> 1;
+    const int cpr = Kp >> 3;
+    const long total = (long)T * ppf * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cpr);
+        long pr = i / cpr;
+        int pi = (int)(pr % ppf);
+        int f = (int)(pr / ppf);
+        // merge-block-major patch index -> (row, col) of the patch grid
+        int iw = pi & 1, ih = (pi >> 1) & 1, blk = pi >> 2;
+        int bw = blk % gwm, bh = blk / gwm;
+        int prow = bh * 2 + ih, pcol = bw * 2 + iw;
+        uint4 o;
+        uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = c * 8 + j;
+            float val = 0.f;
+            if (k < 3 * 2 * PS * PS) {
+                int ch = k / (2 * PS * PS);
+                int rem = k % (PS * PS);  // temporal slice index dropped: both slices are the same frame
+                int py = rem / PS, px = rem % PS;
+                double raw = (double)frames[(((size_t)f * 3 + ch) * H + (prow * PS + py)) * W + (pcol * PS + px)];
+                float r = (float)(raw * 0.00392156862745098);
+                float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+                float sd = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+                val = __fdiv_rn(__fsub_rn(r, mean), sd);
+            }
+            v[j] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+        *reinterpret_cast<uint4*>(dst + ((size_t)f * ppf + pi) * Kp + c * 8) = o;
+    }
+}
+
+extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
+                            const float* std3, hipStream_t stream) {
+    if (!frames || !dst || !mean3 || !std3 || T < 0 || H <= 0 || W <= 0 || (H % 28) || (W % 28) || Kp < 1176 || (Kp & 7))
+        return O3V_ERR_ARG;
+    if (T == 0) return O3V_OK;
+    long total = (long)T * (H / 14) * (W / 14) * (Kp >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (is_u8)
+        hipLaunchKernelGGL(patchify_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
+                           T, H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
+                           H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy sampler (TF:generation/utils.py:2894-2929 + logits_process.py:404-414): fp32 view of the bf16
+// last-token logits, repetition penalty over every id seen so far (prompt + generated; `seen` is a
+// byte map [B,V]), argmax with lowest-index tie break, pad after EOS, margin = top1 - top2.
+// One 1024-thread block per sequence.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(const bf16_t* __restrict__ logits, uint8_t* __restrict__ seen,
+                                                             int* __restrict__ cur_tok, int* __restrict__ finished,
+                                                             int* __restrict__ out_ids, float* __restrict__ margins,
+                                                             const int* __restrict__ eos_ids, int n_eos, int pad_id,
+                                                             int V, int ldl, float rep_penalty, int step, int out_stride) {
+    const int b = blockIdx.x;
+    const bf16_t* lr = logits + (size_t)b * ldl;
+    uint8_t* sr = seen + (size_t)b * V;
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float s = bf2f(lr[i]);
+        if (rep_penalty != 1.0f && sr[i]) s = (s < 0.f) ? s * rep_penalty : s / rep_penalty;
+        if (s > best) {
+            second = best;
+            best = s;
+            bi = i;
+        } else if (s > second) {
+            second = s;
+        }
+    }
+    // wave reduce (value desc, index asc)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            second = fmaxf(best, os);
+            best = ob;
+            bi = oi;
+        } else {
+            second = fmaxf(second, ob);
+        }
+    }
+    __shared__ float sb[16], ss[16];
+    __shared__ int si[16];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sb[w] = best;
+        ss[w] = second;
+        si[w] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            if (sb[k] > best || (sb[k] == best && si[k] < bi)) {
+                second = fmaxf(best, ss[k]);
+                best = sb[k];
+                bi = si[k];
+            } else {
+                second = fmaxf(second, sb[k]);
+            }
+        }
+        int tok = finished[b] ? pad_id : bi;
+        if (!finished[b]) {
+            for (int k = 0; k < n_eos; ++k)
+                if (tok == eos_ids[k]) finished[b] = 1;
+        }
+        if (tok >= 0 && tok < V) sr[tok] = 1;
+        cur_tok[b] = tok;
+        out_ids[(size_t)b * out_stride + step] = tok;
+        if (margins) margins[(size_t)b * out_stride + step] = best - second;
+    }
+}
+
+extern "C" int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
+                                 const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty,
+                                 int step, int out_stride, hipStream_t stream) {
+    if (!logits || !seen || !cur_tok || !finished || !out_ids || B < 0 || V <= 0 || step < 0 || step >= out_stride)
+        return O3V_ERR_ARG;
+    if (B == 0) return O3V_OK;
+    hipLaunchKernelGGL(sample_greedy_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
+                       finished, out_ids, margins, eos_ids, n_eos, pad_id, V, ldl, rep_penalty, step, out_stride);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// mark prompt ids as seen (repetition penalty covers prompt + generated, TF:logits_process.py:404-414)
+__global__ void mark_seen_kernel(const int* __restrict__ ids, uint8_t* __restrict__ seen, int B, int S, int V) {
+    long total = (long)B * S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / S);
+        int id = ids[i];
+        if (id >= 0 && id < V) seen[(size_t)b * V + id] = 1;
+    }
+}
+
+extern "C" int o3v_mark_seen(const int* ids, void* seen, int B, int S, int V, hipStream_t stream) {
+    if (!ids || !seen || B < 0 || S < 0 || V <= 0) return O3V_ERR_ARG;
+    if (B * (long)S == 0) return O3V_OK;
+    int blocks = (int)(((long)B * S + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mark_seen_kernel, dim3(blocks), dim3(256), 0, stream, ids, (uint8_t*)seen, B, S, V);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// decode-step embedding lookup: x[b,:] = table[cur_tok[b],:]
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const uint4* __restrict__ table, const int* __restrict__ tok,
+                                                           uint4* __restrict__ out, int B, int chunks) {
+    long total = (long)B * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % chunks);
+        int b = (int)(i / chunks);
+        out[(size_t)b * chunks + c] = table[(size_t)tok[b] * chunks + c];
+    }
+}
+
+extern "C" int o3v_embed_tokens(const void* table, const int* tok, void* out, int B, int hidden, hipStream_t stream) {
+    if (!table || !tok || !out || B < 0 || hidden <= 0 || (hidden & 7)) return O3V_ERR_ARG;
+    if (B == 0) return O3V_OK;
+    long total = (long)B * (hidden >> 3);
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, tok, (uint4*)out, B,
+                       hidden >> 3);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-token log-prob gather (R:grpo_trainer.py:371-384): logits bf16 [R, V] row r predicts target[r];
+// out[r] = logits[r,target] - logsumexp(logits[r,:]) computed in fp32 (log_softmax of the bf16 logits
+// is done by torch in bf16->fp32 internally; the reference then gathers).  One block per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logprob_gather_kernel(const bf16_t* __restrict__ logits, const int* __restrict__ target,
+                                                             float* __restrict__ out, int V, int ldl) {
+    const int r = blockIdx.x;
+    const bf16_t* lr = logits + (size_t)r * ldl;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) m = fmaxf(m, bf2f(lr[i]));
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) s += expf(bf2f(lr[i]) - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = red[0] + red[1] + red[2] + red[3];
+        int t = target[r];
+        out[r] = (t >= 0 && t < V) ? (bf2f(lr[t]) - m) - logf(s) : 0.f;
+    }
+}
+
+extern "C" int o3v_logprob_gather(const void* logits, const int* target, float* out, int R, int V, int ldl,
+                                  hipStream_t stream) {
+    if (!logits || !target || !out || R < 0 || V <= 0) return O3V_ERR_ARG;
+    if (R == 0) return O3V_OK;
+    hipLaunchKernelGGL(logprob_gather_kernel, dim3(R), dim3(256), 0, stream, (const bf16_t*)logits, target, out, V, ldl);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}

@@ -1,0 +1,225 @@
+// Host-side runtime of libo3v_hip.so: the layer loops of the Qwen2.5-VL ViT, LLM prefill and decode,
+// enqueued kernel by kernel on one HIP stream from C++ (no Python between launches, no allocation, no
+// sync -- the whole forward is graph-capturable).  Arithmetic restated from transformers 5.15.0
+// models/qwen2_5_vl/modeling_qwen2_5_vl.py (TF:) -- see include/o3v.h for the per-entry citations.
+#include <hip/hip_runtime.h>
+
+#include "../../include/o3v.h"
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != O3V_OK) return rc__; \
+    } while (0)
+
+namespace {
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* base;
+    size_t off, cap;
+    void* take(size_t bytes) {
+        size_t o = off;
+        off = align256(off + bytes);
+        return off <= cap ? base + o : nullptr;
+    }
+};
+
+// nn.Linear for any row count: MFMA GEMM above 8 rows, weight-streaming GEMV (in groups of 8 rows) otherwise.
+int linear(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
+           int ldo, int ldr, int epi, o3v_stream_t s) {
+    if (M > 8) return o3v_gemm_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
+    return o3v_gemv_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
+}
+
+}  // namespace
+
+extern "C" int o3v_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------ ViT
+extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
+    if (!d || P <= 0) return 0;
+    const size_t hid = d->hidden, e = 2;
+    const size_t Pm = (size_t)P / d->merge_unit;
+    size_t n = 0;
+    n += align256((size_t)P * hid * e);          // x
+    n += align256((size_t)P * hid * e);          // h
+    n += align256((size_t)P * 3 * hid * e);      // qkv
+    n += align256((size_t)P * hid * e);          // att
+    n += align256((size_t)P * d->inter_pad * e); // mlp
+    n += align256(Pm * hid * d->merge_unit * e); // m1
+    n += align256(Pm * d->out_hidden * e);       // m2
+    return n;
+}
+
+extern "C" int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P, const int* win_idx, const int* rev_idx,
+                               const float* cosT, const float* sinT, const int* tiles_win, int n_tiles_win,
+                               const int* tiles_full, int n_tiles_full, void* workspace, size_t ws_bytes, void* out,
+                               o3v_stream_t s) {
+    if (!d || !pixels || !win_idx || !rev_idx || !cosT || !sinT || !tiles_win || !tiles_full || !workspace || !out)
+        return O3V_ERR_ARG;
+    if (P <= 0 || d->merge_unit <= 0 || (P % d->merge_unit) || d->heads <= 0 || (d->hidden % d->heads)) return O3V_ERR_ARG;
+    if (ws_bytes < o3v_vit_workspace_bytes(d, P)) return O3V_ERR_WORKSPACE;
+    const int hid = d->hidden, H = d->heads, D = hid / H, unit = d->merge_unit, Pm = P / unit, ip = d->inter_pad;
+    Carver cv{(char*)workspace, 0, ws_bytes};
+    char* x = (char*)cv.take((size_t)P * hid * 2);
+    char* h = (char*)cv.take((size_t)P * hid * 2);
+    char* qkv = (char*)cv.take((size_t)P * 3 * hid * 2);
+    char* att = (char*)cv.take((size_t)P * hid * 2);
+    char* mlp = (char*)cv.take((size_t)P * ip * 2);
+    char* m1 = (char*)cv.take((size_t)Pm * hid * unit * 2);
+    char* m2 = (char*)cv.take((size_t)Pm * d->out_hidden * 2);
+    if (!m2) return O3V_ERR_WORKSPACE;
+    const float scale = 1.0f / sqrtf((float)D);
+
+    // patch embed (Conv3d k=s == GEMM over flattened patches), then window order at merge-unit granularity
+    TRY(o3v_gemm_bf16(pixels, d->patch_w, nullptr, nullptr, h, P, hid, d->patch_k_pad, d->patch_k_pad, d->patch_k_pad, hid,
+                      0, O3V_EPI_NONE, s));
+    TRY(o3v_gather_rows(h, win_idx, x, Pm, unit * hid * 2, s));
+
+    for (int i = 0; i < d->depth; ++i) {
+        const o3v_vit_block_w& w = d->blocks[i];
+        const bool full = (d->fullatt_mask >> i) & 1;
+        TRY(o3v_rmsnorm(x, w.norm1, h, P, hid, hid, hid, 1e-6f, s));
+        TRY(o3v_gemm_bf16(h, w.qkv_w, w.qkv_b, nullptr, qkv, P, 3 * hid, hid, hid, hid, 3 * hid, 0, O3V_EPI_NONE, s));
+        TRY(o3v_vit_rope(qkv, cosT, sinT, P, H, D, s));
+        TRY(o3v_attn_tiles(qkv, qkv + (size_t)hid * 2, qkv + (size_t)2 * hid * 2, att, full ? tiles_full : tiles_win,
+                           full ? n_tiles_full : n_tiles_win, H, 1, D, 3L * hid, 3L * hid, D, 0, 3L * hid, D, 0, hid, scale,
+                           s));
+        TRY(o3v_gemm_bf16(att, w.proj_w, w.proj_b, x, x, P, hid, hid, hid, hid, hid, hid, O3V_EPI_RESIDUAL, s));
+        TRY(o3v_rmsnorm(x, w.norm2, h, P, hid, hid, hid, 1e-6f, s));
+        TRY(o3v_gemm_bf16(h, w.gu_w, w.gu_b, nullptr, mlp, P, 2 * ip, hid, hid, hid, ip, 0, O3V_EPI_SWIGLU, s));
+        TRY(o3v_gemm_bf16(mlp, w.down_w, w.down_b, x, x, P, hid, ip, ip, ip, hid, hid, O3V_EPI_RESIDUAL, s));
+    }
+    // merger: RMSNorm -> [P/4, 4*hid] -> Linear+GELU -> Linear -> original token order
+    TRY(o3v_rmsnorm(x, d->ln_q, h, P, hid, hid, hid, 1e-6f, s));
+    const int mh = hid * unit;
+    TRY(linear(h, d->m0_w, d->m0_b, nullptr, m1, Pm, mh, mh, mh, mh, 0, O3V_EPI_GELU, s));
+    TRY(linear(m1, d->m2_w, d->m2_b, nullptr, m2, Pm, d->out_hidden, mh, mh, d->out_hidden, 0, O3V_EPI_NONE, s));
+    TRY(o3v_gather_rows(m2, rev_idx, out, Pm, d->out_hidden * 2, s));
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LLM
+extern "C" size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows) {
+    if (!d || rows <= 0) return 0;
+    const size_t R = rows, H = d->hidden, QD = (size_t)d->heads * d->head_dim, KD = (size_t)d->kv_heads * d->head_dim;
+    size_t n = 0;
+    n += align256(R * H * 2);               // h
+    n += align256(R * (QD + 2 * KD) * 2);   // qkv
+    n += align256(R * QD * 2);              // q (roped)
+    n += align256(R * QD * 2);              // att
+    n += align256(R * d->inter * 2);        // mlp
+    n += align256(R * H * 2);               // normed (head)
+    return n;
+}
+
+namespace {
+struct LlmWs {
+    char *h, *qkv, *q, *att, *mlp, *normed;
+};
+bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w) {
+    const size_t R = rows, H = d->hidden, QD = (size_t)d->heads * d->head_dim, KD = (size_t)d->kv_heads * d->head_dim;
+    Carver cv{(char*)ws, 0, bytes};
+    w.h = (char*)cv.take(R * H * 2);
+    w.qkv = (char*)cv.take(R * (QD + 2 * KD) * 2);
+    w.q = (char*)cv.take(R * QD * 2);
+    w.att = (char*)cv.take(R * QD * 2);
+    w.mlp = (char*)cv.take(R * d->inter * 2);
+    w.normed = (char*)cv.take(R * H * 2);
+    return w.normed != nullptr;
+}
+}  // namespace
+
+extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
+                               int n_tiles, void* kcache, void* vcache, int B, int S, int Tmax, void* workspace,
+                               size_t ws_bytes, o3v_stream_t s) {
+    if (!d || !x || !cosT || !sinT || !tiles || !kcache || !vcache || !workspace) return O3V_ERR_ARG;
+    if (B <= 0 || S <= 0 || S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
+    const int rows = B * S, H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter;
+    const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
+    LlmWs w;
+    if (ws_bytes < o3v_llm_workspace_bytes(d, rows) || !carve_llm(d, rows, workspace, ws_bytes, w)) return O3V_ERR_WORKSPACE;
+    const float scale = 1.0f / sqrtf((float)D);
+    const size_t layer_stride = (size_t)B * Hkv * Tmax * D * 2;
+    for (int l = 0; l < d->layers; ++l) {
+        const o3v_llm_layer_w& lw = d->layer[l];
+        char* kc = (char*)kcache + l * layer_stride;
+        char* vc = (char*)vcache + l * layer_stride;
+        TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
+        TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
+        TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, 0, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
+        TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
+                           (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
+        TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));
+        TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s));
+        TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s));
+    }
+    return O3V_OK;
+}
+
+extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
+                            o3v_stream_t s) {
+    if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
+    const int H = d->hidden;
+    TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
+    for (int r0 = 0; r0 < rows;) {
+        // GEMV groups of <= 8 rows for small row counts; one MFMA GEMM otherwise
+        const int n = (rows > 8) ? rows : rows - r0;
+        TRY(linear((const char*)normed + (size_t)r0 * H * 2, d->lm_head, nullptr, nullptr,
+                   (char*)logits + (size_t)r0 * d->vocab * 2, n, d->vocab, H, H, d->vocab, 0, O3V_EPI_NONE, s));
+        r0 += n;
+    }
+    return O3V_OK;
+}
+
+extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st, int step0, int n_steps,
+                              int skip_last_forward, o3v_stream_t s) {
+    if (!d || !st || !st->x || !st->kcache || !st->vcache || !st->cosT || !st->sinT || !st->logits || !st->seen ||
+        !st->cur_tok || !st->finished || !st->out_ids || !st->part_o || !st->part_ml || !st->workspace)
+        return O3V_ERR_ARG;
+    const int B = st->B;
+    if (B <= 0 || B > 8 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew || st->S + st->Tnew > st->Tmax + 1)
+        return O3V_ERR_ARG;
+    if (st->do_sample && !st->sample_scratch) return O3V_ERR_ARG;
+    const int H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter, V = d->vocab;
+    const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
+    LlmWs w;
+    if (st->ws_bytes < o3v_llm_workspace_bytes(d, B) || !carve_llm(d, B, st->workspace, st->ws_bytes, w))
+        return O3V_ERR_WORKSPACE;
+    const float scale = 1.0f / sqrtf((float)D);
+    const size_t layer_stride = (size_t)B * Hkv * st->Tmax * D * 2;
+    for (int i = 0; i < n_steps; ++i) {
+        const int step = step0 + i;
+        if (st->do_sample)
+            TRY(o3v_sample_top_p(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
+                                 st->n_eos, st->pad_id, B, V, V, st->rep_penalty, st->temperature, st->top_p, st->seed,
+                                 st->row_id, step, st->Tnew, st->sample_scratch, s));
+        else
+            TRY(o3v_sample_greedy(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
+                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, s));
+        if (skip_last_forward && i == n_steps - 1) break;
+        if (st->S + step >= st->Tmax) return O3V_ERR_ARG;
+        // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
+        TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
+        for (int l = 0; l < d->layers; ++l) {
+            const o3v_llm_layer_w& lw = d->layer[l];
+            char* kc = (char*)st->kcache + l * layer_stride;
+            char* vc = (char*)st->vcache + l * layer_stride;
+            TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+            TRY(o3v_gemv_bf16(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, H, NQKV, 0, O3V_EPI_NONE, s));
+            TRY(o3v_qkv_rope_cache(w.qkv, st->cosT, st->sinT, w.q, kc, vc, st->S + step, B, 1, Hq, Hkv, D, st->Tmax, st->Tnew,
+                                   step, s));
+            TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
+                                st->Tmax, st->nsplit, scale, s));
+            TRY(o3v_gemv_bf16(w.att, lw.o_w, nullptr, st->x, st->x, B, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+            TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
+            TRY(o3v_gemv_bf16(w.h, lw.gu_w, nullptr, nullptr, w.mlp, B, 2 * I, H, H, H, I, 0, O3V_EPI_SWIGLU, s));
+            TRY(o3v_gemv_bf16(w.mlp, lw.down_w, nullptr, st->x, st->x, B, H, I, I, I, H, H, O3V_EPI_RESIDUAL, s));
+        }
+        TRY(o3v_llm_head(d, st->x, H, B, w.normed, st->logits, s));
+    }
+    return O3V_OK;
+}
