@@ -1,0 +1,108 @@
+"""ctypes binding of libo3v_hip.so (include/o3v.h).  The library is built in-tree by
+``open_o3_video_amd.build``; there is NO fallback: if it is missing or a call fails we raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libo3v_hip.so")
+
+OK, ERR_ARG, ERR_SHAPE, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3, -4
+_ERR = {ERR_ARG: "bad argument", ERR_SHAPE: "unsupported shape", ERR_LAUNCH: "HIP launch failure",
+        ERR_WORKSPACE: "workspace too small"}
+EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU = 0, 1, 2, 3
+
+vp, ip, fp, i32, i64, f32, u64, sz = (C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_long,
+                                      C.c_float, C.c_uint64, C.c_size_t)
+
+
+class VitBlockW(C.Structure):
+    _fields_ = [(n, vp) for n in ("norm1", "norm2", "qkv_w", "qkv_b", "proj_w", "proj_b", "gu_w", "gu_b", "down_w", "down_b")]
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("depth", i32), ("hidden", i32), ("heads", i32), ("inter_pad", i32), ("out_hidden", i32),
+                ("patch_k_pad", i32), ("merge_unit", i32), ("fullatt_mask", u64), ("patch_w", vp),
+                ("blocks", C.POINTER(VitBlockW)), ("ln_q", vp), ("m0_w", vp), ("m0_b", vp), ("m2_w", vp), ("m2_b", vp)]
+
+
+class LlmLayerW(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w")]
+
+
+class LlmDesc(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
+                ("vocab", i32), ("rms_eps", f32), ("embed", vp), ("layer", C.POINTER(LlmLayerW)), ("final_norm", vp),
+                ("lm_head", vp)]
+
+
+class DecodeState(C.Structure):
+    _fields_ = [("B", i32), ("S", i32), ("Tmax", i32), ("Tnew", i32), ("nsplit", i32), ("pad_id", i32), ("n_eos", i32),
+                ("do_sample", i32), ("rep_penalty", f32), ("temperature", f32), ("top_p", f32), ("seed", u64),
+                ("x", vp), ("kcache", vp), ("vcache", vp), ("cosT", vp), ("sinT", vp), ("logits", vp), ("seen", vp),
+                ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
+                ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
+                ("ws_bytes", sz)]
+
+
+# name -> argtypes (return type int unless listed in _RET)
+SIGNATURES = {
+    "o3v_abi_version": [],
+    "o3v_rmsnorm": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "o3v_vit_rope": [vp, vp, vp, i32, i32, i32, vp],
+    "o3v_mrope_table": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "o3v_qkv_rope_cache": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_gather_rows": [vp, vp, vp, i32, i32, vp],
+    "o3v_embed_scatter": [vp, vp, vp, vp, i32, i32, vp],
+    "o3v_embed_tokens": [vp, vp, vp, i32, i32, vp],
+    "o3v_cast_pad_f32_bf16": [vp, vp, i32, i32, i32, vp],
+    "o3v_patchify": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "o3v_gemm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_gemv_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
+    "o3v_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp],
+    "o3v_sample_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, u64, vp, i32, i32, vp, vp],
+    "o3v_mark_seen": [vp, vp, i32, i32, i32, vp],
+    "o3v_logprob_gather": [vp, vp, vp, i32, i32, i32, vp],
+    "o3v_vit_workspace_bytes": [C.POINTER(VitDesc), i32],
+    "o3v_vit_forward": [C.POINTER(VitDesc), vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, sz, vp, vp],
+    "o3v_llm_workspace_bytes": [C.POINTER(LlmDesc), i32],
+    "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, sz, vp],
+    "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
+    "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
+}
+_RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz}
+
+_lib = None
+
+
+class O3VError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (raises if it has not been built: there is no CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise O3VError(f"{LIB_PATH} not found: run `python -m open_o3_video_amd.build` (hipcc, gfx950)")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
+            fn.argtypes = args
+            fn.restype = _RET.get(name, i32)
+        if lib.o3v_abi_version() != 1:
+            raise O3VError("libo3v_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != OK:
+        raise O3VError(f"{what} failed: {_ERR.get(rc, rc)} ({rc})")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,145 @@
+"""Model configuration read from an HF ``config.json`` (dict) of a Qwen2.5-VL checkpoint."""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import List
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+@dataclass
+class VisionCfg:
+    depth: int
+    hidden_size: int
+    num_heads: int
+    intermediate_size: int
+    out_hidden_size: int
+    patch_size: int = 14
+    temporal_patch_size: int = 2
+    spatial_merge_size: int = 2
+    window_size: int = 112
+    fullatt_block_indexes: List[int] = field(default_factory=lambda: [7, 15, 23, 31])
+    in_channels: int = 3
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+    @property
+    def patch_k(self):
+        return self.in_channels * self.temporal_patch_size * self.patch_size ** 2
+
+    @property
+    def patch_k_pad(self):  # GEMM K must be a multiple of 64
+        return _round_up(self.patch_k, 64)
+
+    @property
+    def inter_pad(self):
+        return _round_up(self.intermediate_size, 64)
+
+    @property
+    def merge_unit(self):
+        return self.spatial_merge_size ** 2
+
+
+@dataclass
+class TextCfg:
+    hidden_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    intermediate_size: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    mrope_section: List[int] = field(default_factory=lambda: [16, 24, 24])
+    tie_word_embeddings: bool = False
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def inter_pad(self):
+        return _round_up(self.intermediate_size, 64)
+
+
+@dataclass
+class O3VConfig:
+    vision: VisionCfg
+    text: TextCfg
+    image_token_id: int = 151655
+    video_token_id: int = 151656
+    vision_start_token_id: int = 151652
+    vision_end_token_id: int = 151653
+    eos_token_id: int = 151645
+    pad_token_id: int = 151643
+    name_or_path: str = ""
+
+    @staticmethod
+    def from_dict(d: dict, name_or_path: str = "") -> "O3VConfig":
+        vc = d["vision_config"]
+        tc = dict(d.get("text_config") or {})
+        # older checkpoints keep the text fields at the top level of config.json
+        for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "intermediate_size",
+                  "vocab_size", "rms_norm_eps", "rope_theta", "tie_word_embeddings"):
+            if k not in tc and k in d:
+                tc[k] = d[k]
+        rope = tc.get("rope_parameters") or tc.get("rope_scaling") or d.get("rope_scaling") or {}
+        mrope = tc.get("mrope_section") or rope.get("mrope_section") or [16, 24, 24]
+        theta = tc.get("rope_theta") or rope.get("rope_theta") or 1000000.0
+        vision = VisionCfg(
+            depth=vc["depth"], hidden_size=vc["hidden_size"], num_heads=vc["num_heads"],
+            intermediate_size=vc["intermediate_size"], out_hidden_size=vc["out_hidden_size"],
+            patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+            spatial_merge_size=vc.get("spatial_merge_size", 2), window_size=vc.get("window_size", 112),
+            fullatt_block_indexes=list(vc.get("fullatt_block_indexes", [7, 15, 23, 31])), in_channels=vc.get("in_channels", 3))
+        text = TextCfg(
+            hidden_size=tc["hidden_size"], num_hidden_layers=tc["num_hidden_layers"],
+            num_attention_heads=tc["num_attention_heads"], num_key_value_heads=tc["num_key_value_heads"],
+            intermediate_size=tc["intermediate_size"], vocab_size=tc["vocab_size"],
+            rms_norm_eps=tc.get("rms_norm_eps", 1e-6), rope_theta=float(theta), mrope_section=list(mrope),
+            tie_word_embeddings=bool(tc.get("tie_word_embeddings", d.get("tie_word_embeddings", False))))
+        eos = d.get("eos_token_id", tc.get("eos_token_id", 151645))
+        if isinstance(eos, (list, tuple)):
+            eos = eos[0]
+        return O3VConfig(vision=vision, text=text,
+                         image_token_id=d.get("image_token_id", 151655), video_token_id=d.get("video_token_id", 151656),
+                         vision_start_token_id=d.get("vision_start_token_id", 151652),
+                         vision_end_token_id=d.get("vision_end_token_id", 151653),
+                         eos_token_id=eos if eos is not None else 151645,
+                         pad_token_id=d.get("pad_token_id", tc.get("pad_token_id", 151643)) or 151643,
+                         name_or_path=name_or_path)
+
+    @staticmethod
+    def from_pretrained(path: str) -> "O3VConfig":
+        with open(os.path.join(path, "config.json")) as f:
+            return O3VConfig.from_dict(json.load(f), name_or_path=path)
+
+
+def qwen25vl_7b_dict():
+    """Public config.json values of Qwen/Qwen2.5-VL-7B-Instruct (the Open-o3-Video base), SURVEY.md section 8."""
+    return {
+        "model_type": "qwen2_5_vl", "image_token_id": 151655, "video_token_id": 151656, "vision_start_token_id": 151652,
+        "vision_end_token_id": 151653, "eos_token_id": 151645, "pad_token_id": 151643, "tie_word_embeddings": False,
+        "vision_config": {"depth": 32, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420,
+                          "out_hidden_size": 3584, "patch_size": 14, "temporal_patch_size": 2, "spatial_merge_size": 2,
+                          "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31], "in_channels": 3},
+        "text_config": {"hidden_size": 3584, "num_hidden_layers": 28, "num_attention_heads": 28, "num_key_value_heads": 4,
+                        "intermediate_size": 18944, "vocab_size": 152064, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+                        "mrope_section": [16, 24, 24], "tie_word_embeddings": False},
+    }
+
+
+def qwen25vl_3b_dict():
+    d = qwen25vl_7b_dict()
+    d["tie_word_embeddings"] = True
+    d["vision_config"] = dict(d["vision_config"], out_hidden_size=2048)
+    d["text_config"] = {"hidden_size": 2048, "num_hidden_layers": 36, "num_attention_heads": 16, "num_key_value_heads": 2,
+                        "intermediate_size": 11008, "vocab_size": 151936, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+                        "mrope_section": [16, 24, 24], "tie_word_embeddings": True}
+    return d

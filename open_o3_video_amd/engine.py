@@ -1,0 +1,361 @@
+"""O3VEngine: the MI355X generate engine (ViT -> merger -> prefill -> decode) over libo3v_hip.so.
+
+Python only plans (index tables, buffers as torch-ROCm tensors, one ctypes call per stage); every FLOP runs
+in the HIP library on the current torch stream.  There is no CPU / eager fallback: without a GPU and the
+built library this raises.
+
+Reference behaviour restated: GenerationMixin.generate/_sample on Qwen2_5_VLForConditionalGeneration as
+the Open-o3-Video trainer and eval drive it (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:581-586,
+R:eval/models/model_vllm.py:103-126); TF = transformers 5.15.0 models/qwen2_5_vl/modeling_qwen2_5_vl.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, indexing
+from .config import O3VConfig
+from .weights import DeviceWeights
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # OPENAI_CLIP_MEAN/STD, TF:models/qwen2_vl/image_processing_qwen2_vl.py:94-101
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class GenerateOutput:
+    sequences: torch.Tensor            # i64 [B, S+T]
+    margins: Optional[torch.Tensor]    # f32 [B, T]: greedy top1-top2 margin / sampled token log-prob
+    n_steps: int
+    timings: dict
+
+
+class O3VEngine:
+    def __init__(self, cfg: O3VConfig, weights: DeviceWeights):
+        if not torch.cuda.is_available():
+            raise _lib.O3VError("O3VEngine needs a ROCm GPU (no CPU path)")
+        _lib.load()
+        self.cfg, self.w = cfg, weights
+        self.dev = weights.device
+        tc = cfg.text
+        D = tc.head_dim
+        # inv_freq exactly as torch computes it on the host (TF:521)
+        inv = 1.0 / (tc.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+        self.inv_freq = inv.to(self.dev)
+        self.axis_of = torch.from_numpy(indexing.mrope_axis_table(tc.mrope_section)).to(self.dev)
+        self.clip_mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.dev)
+        self.clip_std = torch.tensor(CLIP_STD, dtype=torch.float32, device=self.dev)
+        self._vit_plan_cache = {}
+
+    # ------------------------------------------------------------------------------------------ vision
+    def _vit_plan(self, grid_thw):
+        key = indexing._grid_key(grid_thw)
+        p = self._vit_plan_cache.get(key)
+        if p is not None:
+            return p
+        vc = self.cfg.vision
+        widx, cu_win, cu_full, pos = indexing.vision_plan(key, vc.spatial_merge_size, vc.window_size, vc.patch_size)
+        unit = vc.merge_unit
+        P = int(cu_full[-1])
+        # rotary table in window order (TF:125-134, :441-446): fp32, computed as torch does on the host
+        rdim = vc.head_dim // 2
+        inv = 1.0 / (10000.0 ** (torch.arange(0, rdim, 2, dtype=torch.float) / rdim))
+        rot = (torch.from_numpy(pos).unsqueeze(-1) * inv).flatten(1)            # [P, hd/2]
+        wi = torch.from_numpy(widx)
+        rot = rot.reshape(P // unit, unit, -1)[wi].reshape(P, -1)
+        plan = dict(
+            P=P,
+            win_idx=wi.to(torch.int32).to(self.dev),
+            rev_idx=torch.argsort(wi).to(torch.int32).to(self.dev),
+            cos=rot.cos().contiguous().to(self.dev), sin=rot.sin().contiguous().to(self.dev),
+            tiles_win=torch.from_numpy(indexing.segment_tiles(cu_win)).to(self.dev),
+            tiles_full=torch.from_numpy(indexing.segment_tiles(cu_full)).to(self.dev),
+        )
+        if len(self._vit_plan_cache) > 16:
+            self._vit_plan_cache.clear()
+        self._vit_plan_cache[key] = plan
+        return plan
+
+    def pixels_from_processor(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """HF-processor pixel_values f32 [P,1176] -> bf16 [P,Kp] (TF:1090 cast, zero pad)."""
+        vc = self.cfg.vision
+        pv = pixel_values.to(self.dev, torch.float32).contiguous()
+        out = torch.empty((pv.shape[0], vc.patch_k_pad), dtype=torch.bfloat16, device=self.dev)
+        _lib.call("o3v_cast_pad_f32_bf16", _ptr(pv), _ptr(out), pv.shape[0], pv.shape[1], vc.patch_k_pad, _stream())
+        return out
+
+    def pixels_from_frames(self, frames: torch.Tensor):
+        """frames [T,3,H,W] uint8 or f32 (0..255, H,W multiples of 28) -> (bf16 [P,Kp], grid_thw [T,3])."""
+        vc = self.cfg.vision
+        if frames.dim() != 4 or frames.shape[1] != 3:
+            raise ValueError("frames must be [T,3,H,W]")
+        T, _, H, W = frames.shape
+        if H % 28 or W % 28:
+            raise ValueError("frame size must be a multiple of 28 (smart_resize output)")
+        is_u8 = frames.dtype == torch.uint8
+        fr = frames.to(self.dev).contiguous() if is_u8 else frames.to(self.dev, torch.float32).contiguous()
+        P = T * (H // 14) * (W // 14)
+        out = torch.empty((P, vc.patch_k_pad), dtype=torch.bfloat16, device=self.dev)
+        _lib.call("o3v_patchify", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, _ptr(self.clip_mean),
+                  _ptr(self.clip_std), _stream())
+        grid = np.asarray([[1, H // 14, W // 14]] * T, dtype=np.int64)
+        return out, grid
+
+    def vit_forward(self, pixels_bf16: torch.Tensor, grid_thw) -> torch.Tensor:
+        """TF:408-471 -> merged visual tokens bf16 [P/4, out_hidden] in original order."""
+        vc = self.cfg.vision
+        plan = self._vit_plan(grid_thw)
+        P = plan["P"]
+        if pixels_bf16.shape[0] != P or pixels_bf16.shape[1] != vc.patch_k_pad:
+            raise ValueError(f"pixel rows {tuple(pixels_bf16.shape)} do not match grid ({P} patches)")
+        nbytes = _lib.load().o3v_vit_workspace_bytes(C.byref(self.w.vit), P)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        out = torch.empty((P // vc.merge_unit, vc.out_hidden_size), dtype=torch.bfloat16, device=self.dev)
+        _lib.call("o3v_vit_forward", C.byref(self.w.vit), _ptr(pixels_bf16), P, _ptr(plan["win_idx"]), _ptr(plan["rev_idx"]),
+                  _ptr(plan["cos"]), _ptr(plan["sin"]), _ptr(plan["tiles_win"]), plan["tiles_win"].shape[0],
+                  _ptr(plan["tiles_full"]), plan["tiles_full"].shape[0], _ptr(ws), nbytes, _ptr(out), _stream())
+        return out
+
+    # ------------------------------------------------------------------------------------------ text
+    def mrope_table(self, pos3: np.ndarray):
+        """pos3 int [3, T] -> cos, sin bf16 [T, D] on device."""
+        D = self.cfg.text.head_dim
+        T = pos3.shape[1]
+        p = torch.from_numpy(np.ascontiguousarray(pos3.astype(np.int32))).to(self.dev)
+        cos = torch.empty((T, D), dtype=torch.bfloat16, device=self.dev)
+        sin = torch.empty_like(cos)
+        _lib.call("o3v_mrope_table", _ptr(p), _ptr(self.inv_freq), _ptr(self.axis_of), _ptr(cos), _ptr(sin), T, D, _stream())
+        return cos, sin
+
+    def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor]) -> torch.Tensor:
+        src, n_img = indexing.embed_source_rows(input_ids, self.cfg.image_token_id)
+        if n_img and (vis is None or vis.shape[0] != n_img):
+            raise ValueError(f"Image features and image tokens do not match, tokens: {n_img}, "
+                             f"features: {0 if vis is None else vis.shape[0]}")
+        H = self.cfg.text.hidden_size
+        T = src.shape[0]
+        x = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+        s = torch.from_numpy(src).to(self.dev)
+        _lib.call("o3v_embed_scatter", _ptr(self.w.t["l.embed"]), _ptr(vis), _ptr(s), _ptr(x), T, H, _stream())
+        return x
+
+    def alloc_cache(self, B, Tmax):
+        tc = self.cfg.text
+        shape = (tc.num_hidden_layers, B, tc.num_key_value_heads, Tmax, tc.head_dim)
+        return (torch.empty(shape, dtype=torch.bfloat16, device=self.dev),
+                torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
+
+    def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc):
+        """Runs the prompt through the LLM (TF:790-872); x [B*S,H] becomes the last layer's residual stream."""
+        Tmax = kc.shape[3]
+        cos, sin = self.mrope_table(pos3.reshape(3, B * S))
+        tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad)).to(self.dev)
+        nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        _lib.call("o3v_llm_prefill", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
+                  _ptr(kc), _ptr(vc), B, S, Tmax, _ptr(ws), nbytes, _stream())
+        return x
+
+    def head(self, x_rows: torch.Tensor) -> torch.Tensor:
+        """final norm + lm_head: bf16 [R,H] (row stride may exceed H) -> logits bf16 [R,V]."""
+        R = x_rows.shape[0]
+        H, V = self.cfg.text.hidden_size, self.cfg.text.vocab_size
+        normed = torch.empty((R, H), dtype=torch.bfloat16, device=self.dev)
+        logits = torch.empty((R, V), dtype=torch.bfloat16, device=self.dev)
+        _lib.call("o3v_llm_head", C.byref(self.w.llm), _ptr(x_rows), x_rows.stride(0), R, _ptr(normed), _ptr(logits), _stream())
+        return logits
+
+    # ------------------------------------------------------------------------------------------ generate
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
+                 max_new_tokens=16, eos_token_ids: Sequence[int] = (), pad_token_id: Optional[int] = None,
+                 repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
+                 num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
+                 vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 32, return_margins: bool = True,
+                 sync_timings: bool = False) -> GenerateOutput:
+        """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
+        completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out."""
+        cfg, tc = self.cfg, self.cfg.text
+        ids = np.asarray(input_ids.cpu() if torch.is_tensor(input_ids) else input_ids, dtype=np.int64)
+        if ids.ndim == 1:
+            ids = ids[None]
+        B0, S = ids.shape
+        mask = np.ones_like(ids) if attention_mask is None else np.asarray(
+            attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=np.int64)
+        pad = (mask == 0).sum(axis=1)
+        if not all((mask[b, pad[b]:] == 1).all() for b in range(B0)):
+            raise ValueError("only left padding is supported (padding_side='left', R:grpo_trainer.py:546)")
+        G = int(num_return_sequences)
+        B = B0 * G
+        if B > 8:
+            raise ValueError("at most 8 sequences per engine call (decode GEMV batch); shard larger batches")
+        pad_id = cfg.pad_token_id if pad_token_id is None else int(pad_token_id)
+        T = int(max_new_tokens)
+        tm = {}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if sync_timings else None
+
+        def mark(i):
+            if ev is not None:
+                ev[i].record()
+
+        mark(0)
+        # ---- vision (once per prompt batch)
+        vis = vis_embeds
+        grid = None if image_grid_thw is None else np.asarray(
+            image_grid_thw.cpu() if torch.is_tensor(image_grid_thw) else image_grid_thw, dtype=np.int64)
+        if vis is None:
+            if frames is not None:
+                px, grid = self.pixels_from_frames(frames)
+                vis = self.vit_forward(px, grid)
+            elif pixel_values is not None:
+                vis = self.vit_forward(self.pixels_from_processor(pixel_values), grid)
+        mark(1)
+        # ---- positions + prefill (once per prompt)
+        if grid is not None:
+            pos, deltas = indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size)
+        else:
+            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
+            pos, deltas = np.broadcast_to(p1[None], (3, B0, S)).copy(), np.zeros(B0, dtype=np.int64)
+        Tmax = S + T
+        kc, vc = self.alloc_cache(B, Tmax)
+        x = self.embed(ids, vis)
+        if G == 1:
+            self.prefill(x, pos, pad, B0, S, kc, vc)
+        else:
+            kc0, vc0 = self.alloc_cache(B0, Tmax)
+            self.prefill(x, pos, pad, B0, S, kc0, vc0)
+            # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
+            kc[:, :, :, :S].copy_(kc0[:, :, :, :S].repeat_interleave(G, dim=1))
+            vc[:, :, :, :S].copy_(vc0[:, :, :, :S].repeat_interleave(G, dim=1))
+            del kc0, vc0
+        last = x.view(B0, S, -1)[:, -1, :]                      # left padding: every row ends at S-1
+        logits0 = self.head(last)                               # [B0, V]
+        logits = logits0.repeat_interleave(G, dim=0).contiguous() if G > 1 else logits0
+        mark(2)
+        # ---- decode state
+        V, H = tc.vocab_size, tc.hidden_size
+        dpos = indexing.decode_positions(mask, deltas, T)       # [3,B0,T]
+        if G > 1:
+            dpos = np.repeat(dpos, G, axis=1)
+        cosd, sind = self.mrope_table(dpos.reshape(3, B * T))
+        seen = torch.zeros((B, V), dtype=torch.uint8, device=self.dev)
+        ids_rep = np.repeat(ids, G, axis=0) if G > 1 else ids
+        pad_rep = np.repeat(pad, G) if G > 1 else pad
+        if repetition_penalty != 1.0:
+            ids_dev = torch.from_numpy(ids_rep.astype(np.int32)).to(self.dev)
+            _lib.call("o3v_mark_seen", _ptr(ids_dev), _ptr(seen), B, S, V, _stream())
+        cur_tok = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        finished = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        out_ids = torch.full((B, T), pad_id, dtype=torch.int32, device=self.dev)
+        margins = torch.zeros((B, T), dtype=torch.float32, device=self.dev) if return_margins else None
+        eos = torch.tensor(list(eos_token_ids) or [0], dtype=torch.int32, device=self.dev)
+        k_lo = torch.from_numpy(pad_rep.astype(np.int32)).to(self.dev)
+        rid = torch.tensor(list(row_ids) if row_ids is not None else list(range(B)), dtype=torch.int32, device=self.dev)
+        n_rep_total = B * tc.num_attention_heads
+        nsplit = max(1, min(64, (Tmax + 63) // 64, max(1, 1024 // max(1, B * tc.num_key_value_heads))))
+        part_o = torch.empty(n_rep_total * nsplit * tc.head_dim, dtype=torch.float32, device=self.dev)
+        part_ml = torch.empty(n_rep_total * nsplit * 2, dtype=torch.float32, device=self.dev)
+        scratch = torch.empty((B, V), dtype=torch.float32, device=self.dev) if do_sample else None
+        xdec = torch.empty((B, H), dtype=torch.bfloat16, device=self.dev)
+        nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        st = _lib.DecodeState(B=B, S=S, Tmax=Tmax, Tnew=T, nsplit=nsplit, pad_id=pad_id, n_eos=len(eos_token_ids),
+                              do_sample=int(do_sample), rep_penalty=float(repetition_penalty), temperature=float(temperature),
+                              top_p=float(top_p), seed=int(seed) & (2 ** 64 - 1), x=xdec.data_ptr(), kcache=kc.data_ptr(),
+                              vcache=vc.data_ptr(), cosT=cosd.data_ptr(), sinT=sind.data_ptr(), logits=logits.data_ptr(),
+                              seen=seen.data_ptr(), cur_tok=cur_tok.data_ptr(), finished=finished.data_ptr(),
+                              out_ids=out_ids.data_ptr(), margins=0 if margins is None else margins.data_ptr(),
+                              eos_ids=eos.data_ptr(), k_lo=k_lo.data_ptr(), row_id=rid.data_ptr(),
+                              part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
+                              sample_scratch=0 if scratch is None else scratch.data_ptr(), workspace=ws.data_ptr(),
+                              ws_bytes=nbytes)
+        # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
+        done = 0
+        use_eos = len(eos_token_ids) > 0
+        chunk = max(1, int(steps_per_sync)) if use_eos else T
+        while done < T:
+            n = min(chunk, T - done)
+            _lib.call("o3v_llm_decode", C.byref(self.w.llm), C.byref(st), done, n, int(done + n == T), _stream())
+            done += n
+            if use_eos and done < T and bool(finished.all().item()):
+                break
+        mark(3)
+        gen = out_ids[:, :done].to(torch.int64)
+        if use_eos and done > 0:
+            # HF stops at the step where every row has finished: trim trailing all-pad columns generated past it
+            fin_col = self._first_all_finished(gen, eos_token_ids, pad_id)
+            gen = gen[:, :fin_col]
+            done = fin_col
+        prompt = torch.from_numpy(ids_rep).to(self.dev)
+        seqs = torch.cat([prompt, gen], dim=1)
+        if ev is not None:
+            torch.cuda.synchronize()
+            tm = {"vit_ms": ev[0].elapsed_time(ev[1]), "prefill_ms": ev[1].elapsed_time(ev[2]),
+                  "decode_ms": ev[2].elapsed_time(ev[3])}
+        return GenerateOutput(sequences=seqs, margins=None if margins is None else margins[:, :done], n_steps=done,
+                              timings=tm)
+
+    @staticmethod
+    def _first_all_finished(gen: torch.Tensor, eos_ids, pad_id) -> int:
+        """Number of columns HF would have produced: up to and including the step at which the last row hit EOS."""
+        g = gen.cpu().numpy()
+        B, T = g.shape
+        fin_at = np.full(B, T, dtype=np.int64)
+        for b in range(B):
+            hit = np.flatnonzero(np.isin(g[b], list(eos_ids)))
+            if hit.size:
+                fin_at[b] = hit[0] + 1
+        return int(min(T, fin_at.max()))
+
+    # ------------------------------------------------------------------------------------------ logits / logps
+    @torch.no_grad()
+    def forward_logits(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
+                       vis_embeds=None) -> torch.Tensor:
+        """model(input_ids, ...).logits bf16 [B,L,V] (R:grpo_trainer.py:375)."""
+        cfg = self.cfg
+        ids = np.asarray(input_ids.cpu() if torch.is_tensor(input_ids) else input_ids, dtype=np.int64)
+        B, S = ids.shape
+        mask = np.ones_like(ids) if attention_mask is None else np.asarray(
+            attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=np.int64)
+        pad = (mask == 0).sum(axis=1)
+        grid = None if image_grid_thw is None else np.asarray(
+            image_grid_thw.cpu() if torch.is_tensor(image_grid_thw) else image_grid_thw, dtype=np.int64)
+        vis = vis_embeds
+        if vis is None:
+            if frames is not None:
+                px, grid = self.pixels_from_frames(frames)
+                vis = self.vit_forward(px, grid)
+            elif pixel_values is not None:
+                vis = self.vit_forward(self.pixels_from_processor(pixel_values), grid)
+        if grid is not None:
+            pos, _ = indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size)
+        else:
+            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
+            pos = np.broadcast_to(p1[None], (3, B, S)).copy()
+        kc, vc = self.alloc_cache(B, S)
+        x = self.embed(ids, vis)
+        self.prefill(x, pos, pad, B, S, kc, vc)
+        return self.head(x).view(B, S, -1)
+
+    @torch.no_grad()
+    def per_token_logps(self, logits: torch.Tensor, input_ids) -> torch.Tensor:
+        """R:grpo_trainer.py:371-384: log_softmax(logits[:, :-1]) gathered at input_ids[:, 1:] -> f32 [B, L-1]."""
+        B, L, V = logits.shape
+        ids = torch.as_tensor(input_ids).to(self.dev)
+        tgt = ids[:, 1:].to(torch.int32).contiguous().view(-1)
+        lg = logits[:, :-1, :].contiguous().view(-1, V)
+        out = torch.empty(lg.shape[0], dtype=torch.float32, device=self.dev)
+        _lib.call("o3v_logprob_gather", _ptr(lg), _ptr(tgt), _ptr(out), lg.shape[0], V, V, _stream())
+        return out.view(B, L - 1)

@@ -1,0 +1,157 @@
+"""Host-side integer bookkeeping of the generate path (vectorised numpy; results are tiny and cached per grid).
+
+Mirrors what transformers computes on the host before launching kernels (TF: = transformers 5.15.0):
+window permutation and ragged segments of the ViT (TF:vision_utils.py:42-65, :81-127, :130-188), the 3-D M-RoPE
+position index (TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:892-942, :944-1058, :1135-1181) and the tile lists
+the attention kernel consumes.  Parity with the oracle / HF goldens: tests/test_host_logic.py.
+"""
+from __future__ import annotations
+
+from functools import lru_cache
+
+import numpy as np
+
+TILE = 64  # query rows per attention tile (csrc/o3v_attn.hip)
+
+
+def _grid_key(grid_thw):
+    return tuple(tuple(int(v) for v in g) for g in np.asarray(grid_thw).reshape(-1, 3))
+
+
+@lru_cache(maxsize=64)
+def _vision_plan_cached(key, merge, window_size, patch_size):
+    win = window_size // merge // patch_size
+    unit = merge * merge
+    widx, seg_len_win, pos_rows, seg_len_full = [], [], [], []
+    base = 0
+    for (t, h, w) in key:
+        lh, lw = h // merge, w // merge
+        nwh, nww = lh // win + 1, lw // win + 1           # TF:166-169 (a full pad window when divisible)
+        r = np.arange(lh)[:, None]
+        c = np.arange(lw)[None, :]
+        wid = ((r // win) * nww + (c // win)).reshape(-1)  # window id of every merged token, row-major order
+        order = np.argsort(wid, kind="stable")             # tokens of one window stay in row-major order
+        counts = np.bincount(wid, minlength=nwh * nww)
+        counts = counts[counts > 0]                        # TF:187 unique_consecutive drops empty windows
+        for ti in range(t):
+            widx.append(base + ti * lh * lw + order)
+            seg_len_win.append(counts * unit)
+            seg_len_full.append(h * w)
+        # (h, w) of every patch in merge-block-major order (TF:112-127)
+        bh, bw, ih, iw = np.meshgrid(np.arange(lh), np.arange(lw), np.arange(merge), np.arange(merge), indexing="ij")
+        hp = (bh * merge + ih).reshape(-1)
+        wp = (bw * merge + iw).reshape(-1)
+        pos_rows.append(np.tile(np.stack([hp, wp], axis=-1), (t, 1)))
+        base += t * lh * lw
+    window_index = np.concatenate(widx).astype(np.int64)
+    cu_win = np.concatenate([[0], np.cumsum(np.concatenate(seg_len_win))]).astype(np.int32)
+    cu_full = np.concatenate([[0], np.cumsum(seg_len_full)]).astype(np.int32)
+    pos = np.concatenate(pos_rows, axis=0).astype(np.int64)
+    return window_index, cu_win, cu_full, pos
+
+
+def vision_plan(grid_thw, merge=2, window_size=112, patch_size=14):
+    """-> (window_index [P/4] i64, cu_window_seqlens i32, cu_seqlens i32, position_ids [P,2] i64)."""
+    return _vision_plan_cached(_grid_key(grid_thw), merge, window_size, patch_size)
+
+
+def segment_tiles(cu):
+    """Non-causal tiles {q_row0,q_rows,k_row0,k_len,-1,0,0,0} for ragged segments given by cu_seqlens."""
+    out = []
+    for a, e in zip(cu[:-1], cu[1:]):
+        a, e = int(a), int(e)
+        for q0 in range(a, e, TILE):
+            out.append((q0, min(TILE, e - q0), a, e - a, -1, 0, 0, 0))
+    return np.asarray(out, dtype=np.int32).reshape(-1, 8)
+
+
+def prefill_tiles(B, S, pad):
+    """Causal tiles over B left-padded rows of S tokens whose K/V sit in the cache at slots 0..S-1."""
+    out = []
+    for b in range(B):
+        pb = int(pad[b])
+        for q0 in range((pb // TILE) * TILE, S, TILE):
+            out.append((b * S + q0, min(TILE, S - q0), 0, S, q0, pb, b, 0))
+    return np.asarray(out, dtype=np.int32).reshape(-1, 8)
+
+
+def rope_index(input_ids, attention_mask, image_grid_thw, image_token_id, merge=2):
+    """3-D M-RoPE positions for frames-as-images prompts.  Returns (pos [3,B,S] i64, deltas [B] i64, max_pos [B]).
+
+    Text run: arange + cur on all three axes.  Image of (t,h,w): t-axis = cur (+frame index), h-axis = cur + row,
+    w-axis = cur + col over the merged (h/2, w/2) grid, then cur += max(h, w)/2  (TF:1033-1052)."""
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    mask = np.ones_like(ids) if attention_mask is None else np.asarray(attention_mask)
+    grids = [tuple(int(v) for v in g) for g in np.asarray(image_grid_thw).reshape(-1, 3)] if image_grid_thw is not None else []
+    pos = np.zeros((3, B, S), dtype=np.int64)
+    deltas = np.zeros(B, dtype=np.int64)
+    gi = 0
+    for b in range(B):
+        keep = mask[b].astype(bool)
+        row = ids[b][keep]
+        n = row.shape[0]
+        is_img = row == image_token_id
+        out = np.empty((3, n), dtype=np.int64)
+        # run boundaries
+        change = np.flatnonzero(np.diff(is_img.astype(np.int8))) + 1
+        starts = np.concatenate([[0], change])
+        ends = np.concatenate([change, [n]])
+        cur = 0
+        for s, e in zip(starts, ends):
+            if not is_img[s]:
+                L = e - s
+                out[:, s:e] = np.arange(L, dtype=np.int64) + cur
+                cur += L
+                continue
+            # a run of image pads may hold several back-to-back images only if no text separates them; the
+            # reference's prompts always put <|vision_end|> text between images, but handle the general case.
+            p = s
+            while p < e:
+                if gi >= len(grids):
+                    raise ValueError("more image placeholder runs than image_grid_thw rows")
+                t, h, w = grids[gi]
+                gi += 1
+                lh, lw = h // merge, w // merge
+                cnt = t * lh * lw
+                if p + cnt > e:
+                    raise ValueError("Image features and image tokens do not match")
+                tt = np.repeat(np.arange(t), lh * lw)
+                hh = np.tile(np.repeat(np.arange(lh), lw), t)
+                ww = np.tile(np.arange(lw), t * lh)
+                out[0, p:p + cnt] = tt + cur
+                out[1, p:p + cnt] = hh + cur
+                out[2, p:p + cnt] = ww + cur
+                cur += max(h, w) // merge
+                p += cnt
+        pos[:, b, keep] = out
+        deltas[b] = (out.max() + 1 - n) if n else 0
+    if gi != len(grids):
+        raise ValueError("Image features and image tokens do not match")
+    return pos, deltas
+
+
+def decode_positions(attention_mask, deltas, n_new):
+    """Positions of the generated tokens (TF:1164-1174): (#real prompt tokens + t) + delta, same on 3 axes."""
+    mask = np.asarray(attention_mask)
+    n_real = mask.sum(axis=1).astype(np.int64)
+    t = np.arange(n_new, dtype=np.int64)[None, :]
+    p = n_real[:, None] + t + np.asarray(deltas).reshape(-1, 1)
+    return np.broadcast_to(p[None], (3,) + p.shape).copy()  # [3,B,n_new]
+
+
+def embed_source_rows(input_ids, image_token_id):
+    """row >= 0: embedding-table row; row < 0: -(k+1) for the k-th visual token (masked_scatter order)."""
+    ids = np.asarray(input_ids).reshape(-1).astype(np.int64)
+    is_img = ids == image_token_id
+    src = ids.copy()
+    src[is_img] = -(np.arange(int(is_img.sum()), dtype=np.int64) + 1)
+    return src.astype(np.int32), int(is_img.sum())
+
+
+def mrope_axis_table(mrope_section):
+    """axis (0=t,1=h,2=w) of every rotary frequency index (TF:590-596: sections repeat over both halves)."""
+    ax = []
+    for i, n in enumerate(mrope_section):
+        ax += [i % 3] * int(n)
+    return np.asarray(ax, dtype=np.int32)

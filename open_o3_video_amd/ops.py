@@ -1,0 +1,64 @@
+"""Thin torch-tensor wrappers over the per-op entry points of the C ABI (used by the parity tests; the engine
+calls the model-level entry points instead).  Every wrapper launches on the current torch stream."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU  # noqa: F401
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rmsnorm(x, w, eps):
+    out = torch.empty_like(x)
+    _lib.call("o3v_rmsnorm", _p(x), _p(w), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(eps), _s())
+    return out
+
+
+def gemm(a, w, bias=None, res=None, epi=EPI_NONE, force=None):
+    """out = epi(a @ w.T + bias).  force in {None,'gemm','gemv'}."""
+    M, K = a.shape
+    N = w.shape[0]
+    No = N // 2 if epi == EPI_SWIGLU else N
+    out = torch.empty((M, No), dtype=torch.bfloat16, device=a.device)
+    fn = "o3v_gemv_bf16" if (force == "gemv" or (force is None and M <= 8)) else "o3v_gemm_bf16"
+    _lib.call(fn, _p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+              0 if res is None else res.stride(0), epi, _s())
+    return out
+
+
+def vit_rope_(qkv, cos, sin, H, D):
+    _lib.call("o3v_vit_rope", _p(qkv), _p(cos), _p(sin), qkv.shape[0], H, D, _s())
+    return qkv
+
+
+def attn_tiles(q, k, v, tiles, Hq, n_rep, D, q_ts, k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, out, o_ts, scale):
+    _lib.call("o3v_attn_tiles", _p(q), _p(k), _p(v), _p(out), _p(tiles), tiles.shape[0], Hq, n_rep, D, q_ts, k_ts, k_hs,
+              k_bs, v_ts, v_hs, v_bs, o_ts, float(scale), _s())
+    return out
+
+
+def attn_decode(q, kc, vc, k_lo, ctx, nsplit, scale):
+    B, Hq, D = q.shape
+    _, Hkv, Tmax, _ = kc.shape
+    out = torch.empty_like(q)
+    po = torch.empty(B * Hq * nsplit * D, dtype=torch.float32, device=q.device)
+    pm = torch.empty(B * Hq * nsplit * 2, dtype=torch.float32, device=q.device)
+    _lib.call("o3v_attn_decode", _p(q), _p(kc), _p(vc), _p(out), _p(po), _p(pm), _p(k_lo), B, Hq, Hkv, D, ctx, Tmax, nsplit,
+              float(scale), _s())
+    return out
+
+
+def gather_rows(src, idx):
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+    _lib.call("o3v_gather_rows", _p(src), _p(idx), _p(out), idx.shape[0], src.shape[1] * src.element_size(), _s())
+    return out

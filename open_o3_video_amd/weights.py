@@ -1,0 +1,234 @@
+"""Checkpoint -> device weight images for libo3v_hip.so.
+
+Packing done once at load (all bf16, resident in HBM):
+  * fused q|k|v weight and bias of every LLM layer (one GEMM / GEMV instead of three);
+  * gate/up fused and interleaved in 16-row groups so the SwiGLU epilogue finds gate_j and up_j in one lane
+    (csrc/o3v_gemm.hip EPI_SWIGLU); intermediate width zero-padded to a multiple of 64 (ViT 3420 -> 3456);
+  * Conv3d patch-embed weight flattened to [hidden, 1176] and zero-padded to K = 1216.
+Zero padding adds exact zeros to fp32 sums, so results are unchanged.
+
+Accepts HF 5.x names (model.visual.*, model.language_model.*) and the hub names of Qwen2.5-VL checkpoints
+(visual.*, model.layers.*); loads a local safetensors directory (never downloads).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import json
+import os
+from typing import Callable, Dict
+
+import torch
+
+from . import _lib
+from .config import O3VConfig
+
+
+def pack_gate_up(gate: torch.Tensor, up: torch.Tensor, ipad: int) -> torch.Tensor:
+    """[I,K],[I,K] -> [2*ipad,K]: rows 32g..32g+15 = gate[16g..], rows 32g+16..32g+31 = up[16g..] (zero padded)."""
+    I, K = gate.shape[0], (gate.shape[1] if gate.dim() == 2 else 1)
+    g = torch.zeros((ipad,) + tuple(gate.shape[1:]), dtype=gate.dtype, device=gate.device)
+    u = torch.zeros_like(g)
+    g[:I] = gate
+    u[:I] = up
+    tail = tuple(gate.shape[1:])
+    g = g.reshape((ipad // 16, 16) + tail)
+    u = u.reshape((ipad // 16, 16) + tail)
+    return torch.stack([g, u], dim=1).reshape((2 * ipad,) + tail).contiguous()
+
+
+def pad_cols(w: torch.Tensor, kpad: int) -> torch.Tensor:
+    if w.shape[1] == kpad:
+        return w.contiguous()
+    out = torch.zeros((w.shape[0], kpad), dtype=w.dtype, device=w.device)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+class _Getter:
+    def __init__(self, fn: Callable[[str], torch.Tensor], device):
+        self.fn, self.device = fn, device
+
+    def __call__(self, *names):
+        for n in names:
+            try:
+                t = self.fn(n)
+            except KeyError:
+                continue
+            if t is not None:
+                return t.to(device=self.device, dtype=torch.bfloat16)
+        raise KeyError(f"weight not found under any of {names}")
+
+
+class DeviceWeights:
+    """Owns the packed tensors and the ctypes descriptors that point at them."""
+
+    def __init__(self, cfg: O3VConfig, get: Callable[[str], torch.Tensor], device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        g = _Getter(get, self.device)
+        self.t: Dict[str, torch.Tensor] = {}
+        vc, tc = cfg.vision, cfg.text
+
+        def v(name):
+            return g("model.visual." + name, "visual." + name)
+
+        def l(name):
+            return g("model.language_model." + name, "model." + name, "language_model.model." + name)
+
+        keep = self.t
+        # ---- vision
+        pw = v("patch_embed.proj.weight").reshape(vc.hidden_size, -1)
+        keep["v.patch_w"] = pad_cols(pw, vc.patch_k_pad)
+        self.vit_blocks = (_lib.VitBlockW * vc.depth)()
+        for i in range(vc.depth):
+            b = f"blocks.{i}."
+            keep[f"v{i}.norm1"] = v(b + "norm1.weight").contiguous()
+            keep[f"v{i}.norm2"] = v(b + "norm2.weight").contiguous()
+            keep[f"v{i}.qkv_w"] = v(b + "attn.qkv.weight").contiguous()
+            keep[f"v{i}.qkv_b"] = v(b + "attn.qkv.bias").contiguous()
+            keep[f"v{i}.proj_w"] = v(b + "attn.proj.weight").contiguous()
+            keep[f"v{i}.proj_b"] = v(b + "attn.proj.bias").contiguous()
+            keep[f"v{i}.gu_w"] = pack_gate_up(v(b + "mlp.gate_proj.weight"), v(b + "mlp.up_proj.weight"), vc.inter_pad)
+            keep[f"v{i}.gu_b"] = pack_gate_up(v(b + "mlp.gate_proj.bias"), v(b + "mlp.up_proj.bias"), vc.inter_pad)
+            keep[f"v{i}.down_w"] = pad_cols(v(b + "mlp.down_proj.weight"), vc.inter_pad)
+            keep[f"v{i}.down_b"] = v(b + "mlp.down_proj.bias").contiguous()
+            for f in ("norm1", "norm2", "qkv_w", "qkv_b", "proj_w", "proj_b", "gu_w", "gu_b", "down_w", "down_b"):
+                setattr(self.vit_blocks[i], f, keep[f"v{i}.{f}"].data_ptr())
+        keep["v.ln_q"] = v("merger.ln_q.weight").contiguous()
+        keep["v.m0_w"] = v("merger.mlp.0.weight").contiguous()
+        keep["v.m0_b"] = v("merger.mlp.0.bias").contiguous()
+        keep["v.m2_w"] = v("merger.mlp.2.weight").contiguous()
+        keep["v.m2_b"] = v("merger.mlp.2.bias").contiguous()
+        mask = 0
+        for i in vc.fullatt_block_indexes:
+            mask |= 1 << int(i)
+        self.vit = _lib.VitDesc(depth=vc.depth, hidden=vc.hidden_size, heads=vc.num_heads, inter_pad=vc.inter_pad,
+                                out_hidden=vc.out_hidden_size, patch_k_pad=vc.patch_k_pad, merge_unit=vc.merge_unit,
+                                fullatt_mask=mask, patch_w=keep["v.patch_w"].data_ptr(), blocks=self.vit_blocks,
+                                ln_q=keep["v.ln_q"].data_ptr(), m0_w=keep["v.m0_w"].data_ptr(),
+                                m0_b=keep["v.m0_b"].data_ptr(), m2_w=keep["v.m2_w"].data_ptr(),
+                                m2_b=keep["v.m2_b"].data_ptr())
+        # ---- text
+        keep["l.embed"] = l("embed_tokens.weight").contiguous()
+        self.llm_layers = (_lib.LlmLayerW * tc.num_hidden_layers)()
+        for i in range(tc.num_hidden_layers):
+            b = f"layers.{i}."
+            keep[f"l{i}.ln1"] = l(b + "input_layernorm.weight").contiguous()
+            keep[f"l{i}.ln2"] = l(b + "post_attention_layernorm.weight").contiguous()
+            keep[f"l{i}.qkv_w"] = torch.cat([l(b + "self_attn.q_proj.weight"), l(b + "self_attn.k_proj.weight"),
+                                             l(b + "self_attn.v_proj.weight")], dim=0).contiguous()
+            keep[f"l{i}.qkv_b"] = torch.cat([l(b + "self_attn.q_proj.bias"), l(b + "self_attn.k_proj.bias"),
+                                             l(b + "self_attn.v_proj.bias")], dim=0).contiguous()
+            keep[f"l{i}.o_w"] = l(b + "self_attn.o_proj.weight").contiguous()
+            keep[f"l{i}.gu_w"] = pack_gate_up(l(b + "mlp.gate_proj.weight"), l(b + "mlp.up_proj.weight"), tc.inter_pad)
+            keep[f"l{i}.down_w"] = pad_cols(l(b + "mlp.down_proj.weight"), tc.inter_pad)
+            for f in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w"):
+                setattr(self.llm_layers[i], f, keep[f"l{i}.{f}"].data_ptr())
+        keep["l.norm"] = l("norm.weight").contiguous()
+        if tc.tie_word_embeddings:
+            keep["l.head"] = keep["l.embed"]
+        else:
+            try:
+                keep["l.head"] = g("lm_head.weight").contiguous()
+            except KeyError:
+                keep["l.head"] = keep["l.embed"]
+        self.llm = _lib.LlmDesc(hidden=tc.hidden_size, layers=tc.num_hidden_layers, heads=tc.num_attention_heads,
+                                kv_heads=tc.num_key_value_heads, head_dim=tc.head_dim, inter=tc.inter_pad,
+                                vocab=tc.vocab_size, rms_eps=tc.rms_norm_eps, embed=keep["l.embed"].data_ptr(),
+                                layer=self.llm_layers, final_norm=keep["l.norm"].data_ptr(),
+                                lm_head=keep["l.head"].data_ptr())
+        self._check_shapes()
+
+    def _check_shapes(self):
+        vc, tc = self.cfg.vision, self.cfg.text
+        if vc.hidden_size % 64 or tc.hidden_size % 64 or (tc.num_attention_heads * tc.head_dim) % 64:
+            raise _lib.O3VError("hidden sizes must be multiples of 64 for the MFMA GEMM K loop")
+        if vc.head_dim not in (32, 64, 80, 128) or tc.head_dim not in (32, 64, 128):
+            raise _lib.O3VError(f"unsupported head_dim (vision {vc.head_dim}, text {tc.head_dim})")
+        if tc.num_attention_heads // tc.num_key_value_heads > 8:
+            raise _lib.O3VError("GQA group size > 8 not supported by the decode attention kernel")
+
+    def nbytes(self):
+        seen, n = set(), 0
+        for t in self.t.values():
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                n += t.numel() * t.element_size()
+        return n
+
+
+# -------------------------------------------------------------------------------------------- sources of weights
+def getter_from_dict(sd: Dict[str, torch.Tensor]):
+    def get(name):
+        return sd[name]
+    return get
+
+
+def getter_from_safetensors_dir(path: str):
+    """Local HF checkpoint directory (model.safetensors or sharded + index).  Never touches the network."""
+    from safetensors import safe_open
+
+    index = os.path.join(path, "model.safetensors.index.json")
+    if os.path.exists(index):
+        with open(index) as f:
+            wm = json.load(f)["weight_map"]
+    else:
+        wm = {}
+        for fn in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            with safe_open(fn, framework="pt") as f:
+                for k in f.keys():
+                    wm[k] = os.path.basename(fn)
+    if not wm:
+        raise FileNotFoundError(f"no safetensors weights under {path}")
+    handles = {}
+
+    def get(name):
+        fn = wm[name]  # KeyError -> next alias
+        if fn not in handles:
+            handles[fn] = safe_open(os.path.join(path, fn), framework="pt")
+        return handles[fn].get_tensor(name)
+    return get
+
+
+def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02):
+    """Seeded random bf16 weights at the model's true dimensions, generated on the device (benchmarks only:
+    there are no checkpoints offline; throughput does not depend on weight values)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    vc, tc = cfg.vision, cfg.text
+    shapes = {}
+    vh, vi = vc.hidden_size, vc.intermediate_size
+    shapes["model.visual.patch_embed.proj.weight"] = (vh, vc.patch_k)
+    for i in range(vc.depth):
+        b = f"model.visual.blocks.{i}."
+        shapes.update({b + "norm1.weight": (vh,), b + "norm2.weight": (vh,), b + "attn.qkv.weight": (3 * vh, vh),
+                       b + "attn.qkv.bias": (3 * vh,), b + "attn.proj.weight": (vh, vh), b + "attn.proj.bias": (vh,),
+                       b + "mlp.gate_proj.weight": (vi, vh), b + "mlp.gate_proj.bias": (vi,), b + "mlp.up_proj.weight": (vi, vh),
+                       b + "mlp.up_proj.bias": (vi,), b + "mlp.down_proj.weight": (vh, vi), b + "mlp.down_proj.bias": (vh,)})
+    m = "model.visual.merger."
+    mh = vh * vc.merge_unit
+    shapes.update({m + "ln_q.weight": (vh,), m + "mlp.0.weight": (mh, mh), m + "mlp.0.bias": (mh,),
+                   m + "mlp.2.weight": (vc.out_hidden_size, mh), m + "mlp.2.bias": (vc.out_hidden_size,)})
+    H, nh, nkv, D, I, V = (tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim,
+                           tc.intermediate_size, tc.vocab_size)
+    shapes["model.language_model.embed_tokens.weight"] = (V, H)
+    for i in range(tc.num_hidden_layers):
+        b = f"model.language_model.layers.{i}."
+        shapes.update({b + "input_layernorm.weight": (H,), b + "post_attention_layernorm.weight": (H,),
+                       b + "self_attn.q_proj.weight": (nh * D, H), b + "self_attn.q_proj.bias": (nh * D,),
+                       b + "self_attn.k_proj.weight": (nkv * D, H), b + "self_attn.k_proj.bias": (nkv * D,),
+                       b + "self_attn.v_proj.weight": (nkv * D, H), b + "self_attn.v_proj.bias": (nkv * D,),
+                       b + "self_attn.o_proj.weight": (H, nh * D), b + "mlp.gate_proj.weight": (I, H),
+                       b + "mlp.up_proj.weight": (I, H), b + "mlp.down_proj.weight": (H, I)})
+    shapes["model.language_model.norm.weight"] = (H,)
+    shapes["lm_head.weight"] = (V, H)
+
+    def get(name):
+        shape = shapes[name]
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layernorm.weight") \
+                or name.endswith("norm.weight") or name.endswith("ln_q.weight"):
+            return torch.ones(shape, device=device, dtype=torch.bfloat16)
+        t = torch.empty(shape, device=device, dtype=torch.bfloat16)
+        t.normal_(0.0, std, generator=gen)
+        return t
+    return get

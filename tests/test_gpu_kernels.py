@@ -1,0 +1,407 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes) on torch-ROCm tensors and
+compared with plain fp32 torch references that apply the reference's bf16 rounding points.
+Tolerances: bf16 outputs may differ by accumulation order -> 1-2 bf16 ulp (rtol 2^-7) unless stated."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from open_o3_video_amd import _lib
+    _lib.load()
+    return torch.device("cuda")
+
+
+def rb(x):
+    """value after a bf16 materialisation"""
+    return x.to(BF).float()
+
+
+def close_bf16(got, ref, ulps=2, atol=1e-3, frac=1.0):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = atol + ulps * (2.0 ** -8) * ref.abs()
+    bad = (got - ref).abs() > tol
+    rate = bad.float().mean().item()
+    assert rate <= 1.0 - frac, f"{bad.sum().item()} / {bad.numel()} outside tolerance; max err {(got - ref).abs().max().item()}"
+
+
+def test_rmsnorm(dev):
+    from open_o3_video_amd import ops
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(0)
+    for rows, cols in [(1, 64), (5, 128), (37, 1280), (130, 3584), (3, 5120)]:
+        x = (torch.randn(rows, cols, generator=g) * 3).to(BF)
+        w = (1 + 0.1 * torch.randn(cols, generator=g)).to(BF)
+        out = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6)
+        ref = model_ref.rmsnorm(x, w, 1e-6)
+        close_bf16(out, ref, ulps=1, atol=0)
+
+
+def _epi_ref(acc, bias, res, epi):
+    from open_o3_video_amd import ops
+    v = acc + (bias.float() if bias is not None else 0)
+    if epi == ops.EPI_NONE:
+        return rb(v)
+    if epi == ops.EPI_RESIDUAL:
+        return rb(rb(v) + res.float())
+    if epi == ops.EPI_GELU:
+        return rb(torch.nn.functional.gelu(rb(v)))
+    raise AssertionError
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 192, 320), (1, 64, 64), (77, 1280, 1216),
+                                    (515, 3456, 1280), (300, 4608, 3584), (130, 128, 1152)])
+def test_gemm_epilogues(dev, M, N, K):
+    from open_o3_video_amd import ops
+    g = torch.Generator().manual_seed(M * 131 + N)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    acc = a.float() @ w.float().t()
+    for epi, b, r in [(ops.EPI_NONE, None, None), (ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, bias, res),
+                      (ops.EPI_GELU, bias, None)]:
+        out = ops.gemm(a, w, b, r, epi, force="gemm")
+        close_bf16(out, _epi_ref(acc, b, r, epi))
+    # in-place residual (out aliases res), as the engine uses it
+    r2 = res.clone()
+    from open_o3_video_amd import _lib
+    import ctypes as C
+    _lib.call("o3v_gemm_bf16", C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), None, C.c_void_p(r2.data_ptr()),
+              C.c_void_p(r2.data_ptr()), M, N, K, K, K, N, N, ops.EPI_RESIDUAL,
+              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    close_bf16(r2, _epi_ref(acc, None, res, ops.EPI_RESIDUAL))
+
+
+def _swiglu_case(dev, M, I, K, ipad, seed):
+    from open_o3_video_amd import ops
+    from open_o3_video_amd.weights import pack_gate_up
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    wg = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wu = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bg = (0.1 * torch.randn(I, generator=g)).to(BF).to(dev)
+    bu = (0.1 * torch.randn(I, generator=g)).to(BF).to(dev)
+    gate = rb(a.float() @ wg.float().t() + bg.float())
+    up = rb(a.float() @ wu.float().t() + bu.float())
+    ref = rb(rb(torch.nn.functional.silu(gate)) * up)
+    return a, pack_gate_up(wg, wu, ipad), pack_gate_up(bg, bu, ipad), ref
+
+
+@pytest.mark.parametrize("M,I,K", [(130, 428, 320), (64, 96, 64), (257, 1152, 896), (5, 256, 128), (1, 1152, 896), (8, 428, 320)])
+def test_swiglu_gemm_and_gemv(dev, M, I, K):
+    from open_o3_video_amd import ops
+    ipad = (I + 63) // 64 * 64
+    a, w, b, ref = _swiglu_case(dev, M, I, K, ipad, M + I)
+    for force in (["gemm", "gemv"] if M <= 8 else ["gemm"]):
+        out = ops.gemm(a, w, b, None, ops.EPI_SWIGLU, force=force)
+        assert out.shape == (M, ipad)
+        close_bf16(out[:, :I], ref)
+        assert (out[:, I:] == 0).all()  # zero weight/bias pad rows -> silu(0)*0 = 0 exactly
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("N,K", [(64, 128), (4608, 3584), (3584, 18944), (1000, 896), (8192, 1280)])
+def test_gemv(dev, M, N, K):
+    from open_o3_video_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    acc = a.float() @ w.float().t()
+    for epi, b, r in [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, None, res), (ops.EPI_GELU, bias, None)]:
+        out = ops.gemm(a, w, b, r, epi, force="gemv")
+        close_bf16(out, _epi_ref(acc, b, r, epi))
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from open_o3_video_amd import ops, _lib
+    a = torch.zeros(4, 100, dtype=BF, device=dev)
+    w = torch.zeros(8, 100, dtype=BF, device=dev)
+    with pytest.raises(_lib.O3VError):
+        ops.gemm(a, w, force="gemm")  # K % 64 != 0
+    with pytest.raises(_lib.O3VError):
+        ops.gemm(torch.zeros(9, 128, dtype=BF, device=dev), torch.zeros(8, 128, dtype=BF, device=dev), force="gemv")
+
+
+def test_vit_rope(dev):
+    from open_o3_video_amd import ops
+    from oracle.model_ref import rotate_half
+    g = torch.Generator().manual_seed(3)
+    for P, H, D in [(48, 2, 32), (100, 4, 80), (33, 3, 64)]:
+        qkv = torch.randn(P, 3, H, D, generator=g).to(BF)
+        ang = torch.rand(P, D // 2, generator=g) * 20
+        cos, sin = ang.cos(), ang.sin()
+        c = torch.cat([cos, cos], -1)[:, None, :]
+        s = torch.cat([sin, sin], -1)[:, None, :]
+        ref = qkv.clone()
+        for i in (0, 1):
+            x = qkv[:, i].float()
+            ref[:, i] = ((x * c) + (rotate_half(x) * s)).to(BF)
+        out = ops.vit_rope_(qkv.reshape(P, -1).clone().to(dev), cos.contiguous().to(dev), sin.contiguous().to(dev), H, D)
+        assert torch.equal(out.cpu().view(P, 3, H, D), ref)  # same fp32 op order -> bit exact
+
+
+def test_mrope_table_and_qkv_rope_cache(dev):
+    import ctypes as C
+    from open_o3_video_amd import _lib, indexing
+    from oracle import model_ref
+    cfg = {"text_config": {"hidden_size": 896, "num_attention_heads": 7, "rope_theta": 1e6, "mrope_section": [16, 24, 24]}}
+    D, Hq, Hkv, B, S, Tmax = 128, 7, 1, 2, 37, 50
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, 6000, (3, B, S), generator=g)
+    cos_ref, sin_ref = model_ref.mrope_cos_sin(cfg, pos, BF)          # [B,S,D]
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).to(dev)
+    axis = torch.from_numpy(indexing.mrope_axis_table([16, 24, 24])).to(dev)
+    p32 = pos.reshape(3, B * S).to(torch.int32).contiguous().to(dev)
+    cos = torch.empty(B * S, D, dtype=BF, device=dev)
+    sin = torch.empty_like(cos)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.call("o3v_mrope_table", P(p32), P(inv), P(axis), P(cos), P(sin), B * S, D, st)
+    # device cosf/sinf vs torch CPU: allow 1 bf16 ulp on a tiny fraction of entries
+    close_bf16(cos.view(B, S, D), cos_ref, ulps=1, atol=2e-3)
+    close_bf16(sin.view(B, S, D), sin_ref, ulps=1, atol=2e-3)
+    # rope + cache write, using the device table so the comparison is exact
+    qkv = torch.randn(B * S, (Hq + 2 * Hkv) * D, generator=g).to(BF)
+    q, k, v = qkv.view(B, S, Hq + 2 * Hkv, D).split([Hq, Hkv, Hkv], dim=2)
+    c4, s4 = cos.cpu().view(B, S, 1, D), sin.cpu().view(B, S, 1, D)
+    q_ref = (q * c4) + (model_ref.rotate_half(q) * s4)
+    k_ref = (k * c4) + (model_ref.rotate_half(k) * s4)
+    qo = torch.zeros(B * S, Hq, D, dtype=BF, device=dev)
+    kc = torch.zeros(B, Hkv, Tmax, D, dtype=BF, device=dev)
+    vc = torch.zeros_like(kc)
+    qd = qkv.to(dev)
+    _lib.call("o3v_qkv_rope_cache", P(qd), P(cos), P(sin), P(qo), P(kc), P(vc), 0, B * S, S, Hq, Hkv, D, Tmax, S, 0, st)
+    assert torch.equal(qo.cpu().view(B, S, Hq, D), q_ref)
+    assert torch.equal(kc.cpu()[:, :, :S].transpose(1, 2), k_ref)
+    assert torch.equal(vc.cpu()[:, :, :S].transpose(1, 2), v)
+    assert (kc[:, :, S:] == 0).all()
+    # decode form: one token per row at slot S+3, table row offset 3 of a [B,Tnew,D] table
+    Tnew = 5
+    cosd = cos.view(B, S, D)[:, :Tnew].contiguous()
+    sind = sin.view(B, S, D)[:, :Tnew].contiguous()
+    one = qkv.view(B, S, -1)[:, 3].contiguous().to(dev)
+    q1 = torch.zeros(B, Hq, D, dtype=BF, device=dev)
+    _lib.call("o3v_qkv_rope_cache", P(one), P(cosd), P(sind), P(q1), P(kc), P(vc), S + 3, B, 1, Hq, Hkv, D, Tmax, Tnew, 3, st)
+    assert torch.equal(q1.cpu(), q_ref[:, 3])
+    assert torch.equal(kc.cpu()[:, :, S + 3], k_ref[:, 3])
+
+
+def _attn_ref(q, k, v, scale, mask=None):
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return p @ v.float()
+
+
+@pytest.mark.parametrize("H,D,lens", [(4, 80, [12, 16, 48, 64, 100, 480, 1]), (2, 32, [24, 64, 65, 7]), (3, 64, [130, 64]),
+                                      (2, 128, [200, 33])])
+def test_attn_varlen_noncausal(dev, H, D, lens):
+    """ViT attention over ragged segments, q/k/v read in place from the fused qkv buffer."""
+    from open_o3_video_amd import ops, indexing
+    g = torch.Generator().manual_seed(sum(lens) + D)
+    P = sum(lens)
+    qkv = torch.randn(P, 3, H, D, generator=g).to(BF)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tiles = torch.from_numpy(indexing.segment_tiles(cu)).to(dev)
+    qd = qkv.reshape(P, -1).contiguous().to(dev)
+    out = torch.zeros(P, H * D, dtype=BF, device=dev)
+    hid = H * D
+    ops.attn_tiles(qd, qd[:, hid:], qd[:, 2 * hid:], tiles, H, 1, D, 3 * hid, 3 * hid, D, 0, 3 * hid, D, 0, out, hid, D ** -0.5)
+    ref = torch.zeros(P, H, D)
+    for a, e in zip(cu[:-1], cu[1:]):
+        q, k, v = (qkv[a:e, i].transpose(0, 1) for i in range(3))
+        ref[a:e] = _attn_ref(q, k, v, D ** -0.5).transpose(0, 1)
+    close_bf16(out.view(P, H, D), ref, ulps=3, atol=4e-3)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,S,pads", [(7, 1, 128, 150, [0, 13]), (4, 2, 32, 70, [5]), (16, 2, 128, 333, [0]),
+                                             (4, 4, 64, 129, [64, 0, 127])])
+def test_attn_causal_gqa_prefill(dev, Hq, Hkv, D, S, pads):
+    from open_o3_video_amd import ops, indexing
+    B, Tmax = len(pads), S + 9
+    g = torch.Generator().manual_seed(S + D)
+    q = torch.randn(B, S, Hq, D, generator=g).to(BF)
+    k = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    v = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pads)).to(dev)
+    out = torch.zeros(B * S, Hq * D, dtype=BF, device=dev)
+    ops.attn_tiles(q.reshape(B * S, -1).to(dev), k.to(dev), v.to(dev), tiles, Hq, Hq // Hkv, D, Hq * D, D, Tmax * D,
+                   Hkv * Tmax * D, D, Tmax * D, Hkv * Tmax * D, out, Hq * D, D ** -0.5)
+    out = out.view(B, S, Hq, D).cpu()
+    rep = Hq // Hkv
+    for b, pad in enumerate(pads):
+        qi = torch.arange(S)[:, None]
+        kj = torch.arange(S)[None, :]
+        mask = (kj <= qi) & (kj >= pad)
+        kk = k[b, :, :S].repeat_interleave(rep, dim=0)
+        vv = v[b, :, :S].repeat_interleave(rep, dim=0)
+        ref = _attn_ref(q[b].transpose(0, 1), kk, vv, D ** -0.5, mask[None]).transpose(0, 1)  # [S,Hq,D]
+        close_bf16(out[b, pad:], ref[pad:], ulps=3, atol=4e-3)
+
+
+def test_attn_online_softmax_rescale_branch(dev):
+    """Force the running max to jump late (spiked key in the last tile) -- the rescale path must be exact."""
+    from open_o3_video_amd import ops, indexing
+    H, D, L = 1, 128, 256
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(L, 1, D, generator=g).to(BF)
+    k = (0.05 * torch.randn(1, L, D, generator=g)).to(BF)
+    v = torch.randn(1, L, D, generator=g).to(BF)
+    k[0, L - 3] = (q[7, 0].float() * 3).to(BF)  # huge score for query 7 in the last kv tile
+    tiles = torch.from_numpy(indexing.segment_tiles(np.asarray([0, L], dtype=np.int32))).to(dev)
+    out = torch.zeros(L, D, dtype=BF, device=dev)
+    ops.attn_tiles(q.reshape(L, D).to(dev), k.to(dev), v.to(dev), tiles, 1, 1, D, D, D, L * D, 0, D, L * D, 0, out, D, D ** -0.5)
+    ref = _attn_ref(q.transpose(0, 1), k, v, D ** -0.5)[0]
+    close_bf16(out, ref, ulps=3, atol=4e-3)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,ctx,pads,nsplit", [(1, 28, 4, 128, 4700, [0], 64), (2, 14, 2, 128, 333, [0, 40], 5),
+                                                         (3, 4, 2, 32, 17, [0, 3, 16], 1), (2, 16, 2, 128, 64, [0, 0], 3),
+                                                         (8, 4, 4, 64, 200, [0] * 8, 4)])
+def test_attn_decode(dev, B, Hq, Hkv, D, ctx, pads, nsplit):
+    from open_o3_video_amd import ops
+    Tmax = ctx + 11
+    g = torch.Generator().manual_seed(ctx)
+    q = torch.randn(B, Hq, D, generator=g).to(BF)
+    k = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    v = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    out = ops.attn_decode(q.to(dev), k.to(dev), v.to(dev), torch.tensor(pads, dtype=torch.int32, device=dev), ctx, nsplit,
+                          D ** -0.5).cpu()
+    rep = Hq // Hkv
+    for b in range(B):
+        kk = k[b, :, pads[b]:ctx].repeat_interleave(rep, dim=0)
+        vv = v[b, :, pads[b]:ctx].repeat_interleave(rep, dim=0)
+        ref = _attn_ref(q[b][:, None, :], kk, vv, D ** -0.5)[:, 0]
+        close_bf16(out[b], ref, ulps=3, atol=4e-3)
+
+
+def test_patchify_matches_hf_processor(dev, golden_dir):
+    """uint8 frames -> pixel rows: bit-exact against Qwen2VLImageProcessor output (golden G3), after the bf16 cast."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    g = np.load(os.path.join(golden_dir, "g3_patchify.npz"))
+    mean = torch.tensor(g["mean"], dtype=torch.float32, device=dev)
+    std = torch.tensor(g["std"], dtype=torch.float32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for tag in "abc":
+        fr = torch.from_numpy(g[f"{tag}_frames"])
+        T, _, H, W = fr.shape
+        ref = torch.from_numpy(g[f"{tag}_pixel_values"]).to(BF)
+        for is_u8, src in ((1, fr.to(dev)), (0, fr.float().to(dev))):
+            out = torch.full((ref.shape[0], 1216), 7.0, dtype=BF, device=dev)
+            _lib.call("o3v_patchify", P(src), is_u8, P(out), T, H, W, 1216, P(mean), P(std), st)
+            assert torch.equal(out[:, :1176].cpu(), ref)
+            assert (out[:, 1176:] == 0).all()
+        # processor-output path: f32 pixel_values -> bf16 padded
+        pv = torch.from_numpy(g[f"{tag}_pixel_values"]).to(dev)
+        out = torch.empty((pv.shape[0], 1216), dtype=BF, device=dev)
+        _lib.call("o3v_cast_pad_f32_bf16", P(pv), P(out), pv.shape[0], 1176, 1216, st)
+        assert torch.equal(out[:, :1176].cpu(), ref) and (out[:, 1176:] == 0).all()
+
+
+def test_gather_and_embed(dev):
+    import ctypes as C
+    from open_o3_video_amd import ops, _lib
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(50, 256, generator=g).to(BF).to(dev)
+    idx = torch.randperm(50, generator=g).to(torch.int32).to(dev)
+    assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
+    table = torch.randn(300, 128, generator=g).to(BF).to(dev)
+    vis = torch.randn(6, 128, generator=g).to(BF).to(dev)
+    rows = torch.tensor([5, -1, -2, 299, 0, -3, -4, -5, -6, 17], dtype=torch.int32, device=dev)
+    out = torch.empty(10, 128, dtype=BF, device=dev)
+    _lib.call("o3v_embed_scatter", C.c_void_p(table.data_ptr()), C.c_void_p(vis.data_ptr()), C.c_void_p(rows.data_ptr()),
+              C.c_void_p(out.data_ptr()), 10, 128, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ref = torch.stack([table[r] if r >= 0 else vis[-r - 1] for r in rows.tolist()])
+    assert torch.equal(out, ref)
+
+
+def test_sample_greedy_and_logprob(dev):
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(9)
+    B, V, T = 3, 152064, 4
+    logits = (torch.randn(B, V, generator=g) * 4).to(BF)
+    ids = torch.randint(0, V, (B, 50), generator=g)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ld = logits.to(dev)
+    for pen in (1.0, 1.05):
+        seen = torch.zeros(B, V, dtype=torch.uint8, device=dev)
+        idd = ids.to(torch.int32).to(dev)
+        _lib.call("o3v_mark_seen", P(idd), P(seen), B, 50, V, st)
+        cur = torch.zeros(B, dtype=torch.int32, device=dev)
+        fin = torch.tensor([0, 1, 0], dtype=torch.int32, device=dev)
+        out = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+        mar = torch.zeros(B, T, device=dev)
+        eos = torch.tensor([V + 5], dtype=torch.int32, device=dev)
+        _lib.call("o3v_sample_greedy", P(ld), P(seen), P(cur), P(fin), P(out), P(mar), P(eos), 1, 777, B, V, V, pen, 2, T, st)
+        sc = model_ref.repetition_penalty(logits.float(), ids, pen) if pen != 1.0 else logits.float()
+        top2 = sc.topk(2, dim=-1)
+        exp = top2.indices[:, 0].clone()
+        exp[1] = 777  # finished row -> pad
+        assert out[:, 2].cpu().tolist() == exp.tolist()
+        np.testing.assert_allclose(mar[:, 2].cpu().numpy(), (top2.values[:, 0] - top2.values[:, 1]).numpy(), rtol=0, atol=1e-6)
+        assert seen[0, exp[0]].item() == 1
+    # log-prob gather
+    tgt = torch.randint(0, V, (B,), generator=g).to(torch.int32)
+    out = torch.empty(B, device=dev)
+    _lib.call("o3v_logprob_gather", P(ld), P(tgt.to(dev)), P(out), B, V, V, st)
+    ref = torch.log_softmax(logits.float(), dim=-1).gather(1, tgt.long()[:, None])[:, 0]
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_sample_top_p_support_and_frequencies(dev):
+    """Sampled ids must lie inside the reference top-p set (TF TopPLogitsWarper), and frequencies must follow the
+    renormalised distribution (chi-square-ish bound on a small vocabulary)."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(4)
+    V, B, N = 64, 8, 400
+    logits = (torch.randn(1, V, generator=g) * 2).to(BF).repeat(B, 1)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ld = logits.to(dev)
+    for top_p, temp in [(0.9, 1.0), (0.5, 0.7), (1.0, 1.0)]:
+        sc = model_ref.temperature_warp(logits[:1].float(), temp)
+        kept = torch.isfinite(model_ref.top_p_warp(sc, top_p)[0]) if top_p < 1 else torch.ones(V, dtype=torch.bool)
+        probs = torch.softmax(sc[0].masked_fill(~kept, float("-inf")), dim=-1)
+        counts = torch.zeros(V)
+        out = torch.zeros(B, N, dtype=torch.int32, device=dev)
+        lp = torch.zeros(B, N, device=dev)
+        seen = torch.zeros(B, V, dtype=torch.uint8, device=dev)
+        cur = torch.zeros(B, dtype=torch.int32, device=dev)
+        fin = torch.zeros(B, dtype=torch.int32, device=dev)
+        eos = torch.tensor([V + 1], dtype=torch.int32, device=dev)
+        scratch = torch.empty(B, V, device=dev)
+        rid = torch.arange(B, dtype=torch.int32, device=dev)
+        for step in range(N):
+            _lib.call("o3v_sample_top_p", P(ld), P(seen), P(cur), P(fin), P(out), P(lp), P(eos), 1, 0, B, V, V, 1.0, temp,
+                      top_p, 1234, P(rid), step, N, P(scratch), st)
+        o = out.cpu().long().view(-1)
+        assert kept[o].all(), "sampled a token outside the top-p set"
+        counts = torch.bincount(o, minlength=V).float()
+        freq = counts / counts.sum()
+        assert (freq - probs).abs().max().item() < 0.03
+        # reproducible per (seed,row,step); different rows differ
+        out2 = torch.zeros_like(out)
+        _lib.call("o3v_sample_top_p", P(ld), P(seen), P(cur), P(fin), P(out2), P(lp), P(eos), 1, 0, B, V, V, 1.0, temp,
+                  top_p, 1234, P(rid), 5, N, P(scratch), st)
+        assert torch.equal(out2[:, 5], out[:, 5])

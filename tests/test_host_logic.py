@@ -1,0 +1,141 @@
+"""CPU tests of the product's host-side logic (open_o3_video_amd/indexing.py, config, weight packing) against the
+HF/reference goldens and the oracle, and of the C-ABI library: it must load and export every symbol that
+include/o3v.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_models as fm
+from open_o3_video_amd import _lib, indexing
+from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict, qwen25vl_7b_dict
+from oracle import index_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_vision_plan_matches_hf(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_vit_index.npz"))
+    for t in sorted({k.split("_")[0] for k in g.files}):
+        wi, cu_win, cu_full, pos = indexing.vision_plan(g[f"{t}_grid"])
+        assert np.array_equal(wi, g[f"{t}_window_index"]), t
+        assert np.array_equal(cu_win, g[f"{t}_cu_window"]), t
+        assert np.array_equal(cu_full, g[f"{t}_cu_full"]), t
+        assert np.array_equal(pos, g[f"{t}_pos"]), t
+
+
+def test_canonical_shapes_from_survey():
+    # TRAIN-RES 16x30 -> 8 windows (6x64, 2x48); EVAL-RES 26x46 -> 24 windows
+    _, cu, _, _ = indexing.vision_plan([[1, 16, 30]])
+    assert sorted(np.diff(cu).tolist()) == [48, 48] + [64] * 6
+    _, cu, _, _ = indexing.vision_plan([[1, 26, 46]])
+    lens = np.diff(cu).tolist()
+    assert len(lens) == 24 and sorted(set(lens)) == [12, 16, 48, 64]
+
+
+def test_rope_index_matches_hf(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_rope_index.npz"))
+    cfg = fm.tiny_config()
+    for t in sorted({k.split("_")[0] for k in g.files}):
+        pos, delta = indexing.rope_index(g[f"{t}_ids"], g[f"{t}_mask"], g[f"{t}_grid"], cfg["image_token_id"])
+        assert np.array_equal(pos, g[f"{t}_pos"]), t
+        assert np.array_equal(delta.reshape(-1, 1), g[f"{t}_delta"]), t
+
+
+def test_rope_index_errors():
+    cfg = fm.tiny_config()
+    ids = fm.make_prompt(cfg, [(1, 4, 6)])
+    with pytest.raises(ValueError):
+        indexing.rope_index([ids], None, [[1, 4, 8]], cfg["image_token_id"])       # wrong grid
+    with pytest.raises(ValueError):
+        indexing.rope_index([ids], None, [[1, 4, 6], [1, 4, 6]], cfg["image_token_id"])  # unused grid
+
+
+def test_decode_positions_follow_hf_rule():
+    mask = np.asarray([[0, 0, 1, 1, 1], [1, 1, 1, 1, 1]])
+    d = indexing.decode_positions(mask, np.asarray([-2, 0]), 3)
+    assert d.shape == (3, 2, 3)
+    assert d[0].tolist() == [[1, 2, 3], [5, 6, 7]] and np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
+
+
+def test_tiles():
+    t = indexing.segment_tiles(np.asarray([0, 12, 76, 206]))
+    assert t.tolist() == [[0, 12, 0, 12, -1, 0, 0, 0], [12, 64, 12, 64, -1, 0, 0, 0], [76, 64, 76, 130, -1, 0, 0, 0],
+                          [140, 64, 76, 130, -1, 0, 0, 0], [204, 2, 76, 130, -1, 0, 0, 0]]
+    p = indexing.prefill_tiles(2, 100, [0, 70])
+    assert p.tolist() == [[0, 64, 0, 100, 0, 0, 0, 0], [64, 36, 0, 100, 64, 0, 0, 0], [164, 36, 0, 100, 64, 70, 1, 0]]
+    assert indexing.segment_tiles(np.asarray([0])).shape == (0, 8)
+
+
+def test_embed_source_rows():
+    src, n = indexing.embed_source_rows([[5, 500, 500, 7], [500, 1, 2, 500]], 500)
+    assert n == 4 and src.tolist() == [5, -1, -2, 7, -3, 1, 2, -4]
+
+
+def test_config_parsing():
+    c = O3VConfig.from_dict(qwen25vl_7b_dict())
+    assert (c.vision.head_dim, c.vision.inter_pad, c.vision.patch_k, c.vision.patch_k_pad) == (80, 3456, 1176, 1216)
+    assert (c.text.head_dim, c.text.num_attention_heads // c.text.num_key_value_heads) == (128, 7)
+    c3 = O3VConfig.from_dict(qwen25vl_3b_dict())
+    assert c3.text.tie_word_embeddings and c3.text.head_dim == 128
+    # hub-style flat config (text fields at top level, rope_scaling.mrope_section)
+    flat = dict(qwen25vl_7b_dict()["text_config"], vision_config=qwen25vl_7b_dict()["vision_config"],
+                rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]})
+    flat.pop("mrope_section")
+    cf = O3VConfig.from_dict(flat)
+    assert cf.text.mrope_section == [16, 24, 24] and cf.text.hidden_size == 3584
+    t = O3VConfig.from_dict(fm.tiny_config())
+    assert t.image_token_id == 500 and t.pad_token_id == 511
+
+
+def test_pack_gate_up_layout():
+    from open_o3_video_amd.weights import pack_gate_up, pad_cols
+    g = torch.arange(40 * 3, dtype=torch.float32).reshape(40, 3)
+    u = -g
+    p = pack_gate_up(g, u, 64)
+    assert p.shape == (128, 3)
+    for j in range(64):
+        grow = (j // 16) * 32 + j % 16
+        assert torch.equal(p[grow], g[j] if j < 40 else torch.zeros(3))
+        assert torch.equal(p[grow + 16], u[j] if j < 40 else torch.zeros(3))
+    b = pack_gate_up(torch.arange(40.0), torch.arange(40.0) + 100, 64)
+    assert b.shape == (128,) and b[16].item() == 100 and b[32].item() == 16
+    assert pad_cols(torch.ones(2, 5), 8)[:, 5:].abs().sum() == 0
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "o3v.h")).read()
+    declared = set(re.findall(r"\b(o3v_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"o3v_stream_t"}
+    assert len(declared) >= 24
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/o3v.h but not exported"
+    assert set(_lib.SIGNATURES) == declared
+    assert _lib.load().o3v_abi_version() == 1
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Error behaviour of the boundary: bad arguments are rejected before any launch."""
+    lib = _lib.load()
+    assert lib.o3v_rmsnorm(None, None, None, 1, 64, 64, 64, 1e-6, None) == _lib.ERR_ARG
+    assert lib.o3v_gemm_bf16(None, None, None, None, None, 1, 1, 64, 64, 64, 1, 0, 0, None) == _lib.ERR_ARG
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.o3v_gemm_bf16(p, p, None, None, p, 4, 8, 100, 100, 100, 8, 0, 0, None) == _lib.ERR_SHAPE
+    assert lib.o3v_gemv_bf16(p, p, None, None, p, 9, 8, 64, 64, 64, 8, 0, 0, None) == _lib.ERR_SHAPE
+    assert lib.o3v_gemm_bf16(p, p, None, None, p, 0, 8, 64, 64, 64, 8, 0, 0, None) == _lib.OK  # empty input
+    assert lib.o3v_rmsnorm(p, p, p, 0, 64, 64, 64, 1e-6, None) == _lib.OK
+    assert lib.o3v_attn_tiles(p, p, p, p, p, 0, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.OK
+    assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 4, 1, 48, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_SHAPE
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from open_o3_video_amd.engine import O3VEngine
+    with pytest.raises(Exception):
+        O3VEngine(O3VConfig.from_dict(fm.tiny_config()), None)
