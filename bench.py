@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X generate path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic video: fused frame pipeline (uint8 frames already in HBM
+-> normalise/patchify) -> ViT -> merger -> LLM prefill -> greedy grounded-CoT decode of --new-tokens tokens with
+EOS suppressed (R:eval/inference_example.py:28 stop_token_ids=[]), Qwen2.5-VL-7B dimensions, 32 frames at the
+reference's training resolution 224x420 (SURVEY.md section 8 TRAIN-RES; S = 4490 prompt tokens), repetition
+penalty 1.05 (R:eval/models/model_vllm.py:30).  Weights: seeded random bf16 at true 7B dims (no checkpoints
+offline; throughput does not depend on weight values).  value = generated tokens / wall time, whole job.
+
+Multi-GPU (torchrun, one process per GPU): every rank owns a replica and its own videos (weak scaling, no data-path
+collective -- the eval path shards by independent videos); timing is bracketed by barrier +
+synchronize and reduced with MAX over ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_prompt(cfg, n_frames, tok_per_frame, S_target, seed=1234):
+    """Synthetic frames-as-images prompt with the real special ids."""
+    g = np.random.default_rng(seed)
+    per = 12 + 1 + tok_per_frame + 1 + 1
+    fixed = n_frames * per
+    pre = max(8, (S_target - fixed) * 7 // 8)
+    post = max(4, S_target - fixed - pre)
+
+    def text(n):
+        return g.integers(1000, 150000 if cfg.text.vocab_size > 150000 else cfg.text.vocab_size // 2, n).tolist()
+
+    ids = text(pre)
+    for _ in range(n_frames):
+        ids += text(12) + [cfg.vision_start_token_id] + [cfg.image_token_id] * tok_per_frame + [cfg.vision_end_token_id] + text(1)
+    ids += text(post)
+    return ids
+
+
+def cpu_baseline(cfg_dict, n_frames, H, W, S, new_tokens, budget_layers=2):
+    """The CPU oracle (oracle/model_ref.py, same torch-CPU ops as the HF bf16 path) timed on this box's host cores on
+    a bounded sample: true 7B widths, `budget_layers` of the 32 ViT blocks / 28 LLM layers, 4 frames for the ViT,
+    S/8 prompt tokens for prefill, 4 decode steps; per-layer times are scaled to the full depth/length."""
+    import copy
+    from oracle import model_ref, index_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixture_models as fm
+    cd = copy.deepcopy(cfg_dict)
+    full_v, full_l = cd["vision_config"]["depth"], cd["text_config"]["num_hidden_layers"]
+    cd["vision_config"]["depth"] = budget_layers
+    cd["vision_config"]["fullatt_block_indexes"] = [budget_layers - 1]
+    cd["text_config"]["num_hidden_layers"] = budget_layers
+    g = torch.Generator().manual_seed(0)
+    W_ = {}
+    for name, shape, kind in fm.weight_specs(cd):
+        t = torch.empty(shape, dtype=torch.bfloat16)
+        if kind == "norm":
+            t.fill_(1.0)
+        else:
+            t.normal_(0, 0.02, generator=g)
+        W_[name] = t
+    dt = torch.bfloat16
+    nf = 4
+    frames = torch.randint(0, 256, (nf, 3, H, W), generator=g, dtype=torch.uint8)
+    mean = np.asarray(index_ref.CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.asarray(index_ref.CLIP_STD, dtype=np.float32)[None, :, None, None]
+    xf = ((frames.numpy().astype(np.float64) / 255.0).astype(np.float32) - mean) / std
+    pv, grid = index_ref.patchify_frames(xf.astype(np.float32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model_ref.vit_forward(W_, cd, torch.from_numpy(pv), grid, dt)
+    t_vit = (time.perf_counter() - t0) * (n_frames / nf) * (full_v / budget_layers)
+    Ss = max(64, S // 8)
+    tc = cd["text_config"]
+    x = torch.randn(1, Ss, tc["hidden_size"], generator=g).to(dt)
+    pos = torch.arange(Ss).view(1, 1, Ss).expand(3, 1, Ss).contiguous()
+    cache = model_ref.KVCache(budget_layers)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model_ref.text_forward(W_, cd, x, pos, torch.ones(1, Ss, dtype=torch.long), cache, dt)
+    t_pre_sample = time.perf_counter() - t0
+    # linear part scales with S, attention part with S^2: bound from below by linear scaling (favours the CPU)
+    t_prefill = t_pre_sample * (S / Ss) * (full_l / budget_layers)
+    head = model_ref.lm_head_weight(W_, cd).to(dt)
+    steps = 4
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(steps):
+            xe = torch.randn(1, 1, tc["hidden_size"], generator=g).to(dt)
+            p = torch.full((3, 1, 1), Ss + i)
+            h = model_ref.text_forward(W_, cd, xe, p, torch.ones(1, Ss + i + 1, dtype=torch.long), cache, dt)
+            torch.nn.functional.linear(h[:, -1], head).float().argmax(-1)
+    t_step_sample = (time.perf_counter() - t0) / steps
+    # per-step: layers scale with depth, lm_head does not; estimate head share by timing it alone
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(2):
+            torch.nn.functional.linear(h[:, -1], head)
+    t_head = (time.perf_counter() - t0) / 2
+    t_step = (t_step_sample - t_head) * (full_l / budget_layers) + t_head
+    total = t_vit + t_prefill + new_tokens * t_step
+    return {
+        "value": round(new_tokens / total, 4), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle/model_ref.py (torch-CPU bf16, same ops as HF transformers Qwen2_5_VL) at true 7B widths: "
+                   f"{budget_layers}/{full_v} ViT blocks on {nf}/{n_frames} frames, {budget_layers}/{full_l} LLM layers on "
+                   f"{Ss}/{S} prompt tokens, {steps} decode steps + lm_head; scaled linearly to full depth/length "
+                   f"(est. vit {t_vit:.1f}s prefill {t_prefill:.1f}s step {t_step * 1e3:.0f}ms)"),
+    }
+
+
+def kernel_roofline(eng, reps=3):
+    """Dominant kernel of the decode loop = the weight-streaming GEMV (csrc/o3v_gemm.hip gemv_bf16_kernel); its
+    largest instance is the fused gate/up projection: algorithmic bytes per launch = 2*I*H*2 B of weights (+x, out).
+    Timed with HIP events on the launch stream, rotating over all layers so every launch streams cold weights."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    tc = eng.cfg.text
+    H, I, L = tc.hidden_size, tc.inter_pad, tc.num_hidden_layers
+    x = torch.randn(1, H, device=eng.dev).to(torch.bfloat16)
+    out = torch.empty(1, I, dtype=torch.bfloat16, device=eng.dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        for l in range(L):
+            _lib.call("o3v_gemv_bf16", C.c_void_p(x.data_ptr()), C.c_void_p(eng.w.t[f"l{l}.gu_w"].data_ptr()), None, None,
+                      C.c_void_p(out.data_ptr()), 1, 2 * I, H, H, H, I, 0, _lib.EPI_SWIGLU, st)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    avg_ms = e0.elapsed_time(e1) / (reps * L)
+    bytes_per_launch = 2 * I * H * 2 + H * 2 + I * 2
+    ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=4,SWIGLU> (LLM gate/up projection, decode)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--new-tokens", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--res", default="train", choices=["train", "eval"])
+    ap.add_argument("--model", default="7b", choices=["7b", "3b"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        dist = dist_
+
+    from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict, qwen25vl_7b_dict
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, random_getter
+
+    cfg_dict = qwen25vl_7b_dict() if args.model == "7b" else qwen25vl_3b_dict()
+    cfg = O3VConfig.from_dict(cfg_dict)
+    dev = torch.device("cuda", local_rank)
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
+    Hres, Wres = (224, 420) if args.res == "train" else (364, 644)
+    tpf = (Hres // 28) * (Wres // 28)
+    S = 4490 if args.res == "train" else 10218
+    if args.frames != 32:
+        S = args.frames * (tpf + 15) + 170
+    ids = build_prompt(cfg, args.frames, tpf, S)
+    S = len(ids)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    videos = [torch.randint(0, 256, (args.frames, 3, Hres, Wres), generator=gen, dtype=torch.uint8, device=dev)
+              for _ in range(2)]  # resident in HBM before the timed region
+
+    def step(i, timings=False):
+        return eng.generate([ids], None, frames=videos[i % len(videos)], max_new_tokens=args.new_tokens, eos_token_ids=(),
+                            repetition_penalty=1.05, return_margins=False, sync_timings=timings)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.sequences.shape[1] == S + args.new_tokens
+
+    # per-stage breakdown (one extra, untimed, synchronised step)
+    stages = step(0, timings=True).timings
+    roof = None if args.no_roofline else kernel_roofline(eng)
+
+    if rank == 0:
+        total_tokens = world * args.steps * args.new_tokens
+        ms_per_step = dt / args.steps * 1e3
+        tc = cfg.text
+        wbytes = sum(eng.w.t[f"l{l}.{k}"].numel() * 2 for l in range(tc.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
+        wbytes += eng.w.t["l.head"].numel() * 2
+        kv_bytes = 2 * tc.num_hidden_layers * tc.num_key_value_heads * tc.head_dim * 2 * (S + args.new_tokens / 2)
+        dec_ms = stages.get("decode_ms", 0.0) / max(1, args.new_tokens)
+        rec = {
+            "metric": "grounded_cot_tokens_per_sec", "value": round(total_tokens / dt, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen2.5-VL-{args.model.upper()} dims, {args.frames} frames {Hres}x{Wres} -> "
+                                   f"{args.frames * tpf} visual tokens, prompt S={S}, greedy decode {args.new_tokens} new tokens "
+                                   f"(EOS suppressed, repetition_penalty 1.05), batch 1 per GPU, random-init bf16 weights",
+                       "parallelism": f"dp{world} (replica per GPU, independent videos, no data-path collective)"},
+            "videos_per_min": round(world * args.steps / dt * 60.0, 2),
+            "stage_ms": {k: round(v, 2) for k, v in stages.items()},
+            "decode_tokens_per_sec_per_gpu": round(1e3 / dec_ms, 1) if dec_ms else None,
+            "decode_step_hbm": {"algorithmic_bytes": int(wbytes + kv_bytes), "ms": round(dec_ms, 4),
+                                "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
+                                "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None},
+        }
+        if roof:
+            rec["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(cfg_dict, args.frames, Hres, Wres, S, args.new_tokens)
+        print(json.dumps(rec), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
