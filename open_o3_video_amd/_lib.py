@@ -57,7 +57,7 @@ SIGNATURES = {
     "o3v_embed_scatter": [vp, vp, vp, vp, i32, i32, vp],
     "o3v_embed_tokens": [vp, vp, vp, i32, i32, vp],
     "o3v_cast_pad_f32_bf16": [vp, vp, i32, i32, i32, vp],
-    "o3v_patchify": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "o3v_patchify": [vp, i32, vp, i32, i32, i32, i32, fp, fp, vp],
     "o3v_gemm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
@@ -88,6 +88,10 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise O3VError(f"{LIB_PATH} not found: run `python -m open_o3_video_amd.build` (hipcc, gfx950)")
+        # torch-ROCm bundles its own libamdhip64.so.7; import it FIRST so our DT_NEEDED entry resolves to the runtime
+        # that owns torch's streams and allocations (two HIP runtimes in one process cannot launch on each other's
+        # streams: "HIP launch failure").
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge

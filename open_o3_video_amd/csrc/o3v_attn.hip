@@ -347,7 +347,7 @@ extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void*
     const float sl2 = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, Hq), block(256);
 #define O3V_AT(DD)                                                                                                    \
-    hipLaunchKernelGGL((attn_tiles_kernel<DD>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
+    O3V_KLAUNCH((attn_tiles_kernel<DD>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
                        (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, (const TileDesc*)tiles, q_ts, \
                        k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2)
     switch (D) {
@@ -375,9 +375,9 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
     const long k_hs = (long)Tmax * D, k_bs = (long)Hkv * Tmax * D;
     dim3 grid(nsplit, Hkv, B), block(256);
 #define O3V_AD(DD)                                                                                                     \
-    hipLaunchKernelGGL((attn_decode_kernel<DD>), grid, block, 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc,           \
+    O3V_KLAUNCH((attn_decode_kernel<DD>), grid, block, 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc,           \
                        (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2);                \
-    hipLaunchKernelGGL((attn_decode_combine_kernel<DD>), dim3(B* Hq), dim3(DD < 64 ? 64 : DD), 0, stream, part_o,      \
+    O3V_KLAUNCH((attn_decode_combine_kernel<DD>), dim3(B* Hq), dim3(DD < 64 ? 64 : DD), 0, stream, part_o,      \
                        part_ml, (bf16_t*)out, nsplit)
     switch (D) {
         case 32: O3V_AD(32); break;

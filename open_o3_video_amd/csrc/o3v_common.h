@@ -50,6 +50,14 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 #define O3V_ERR_SHAPE (-2)
 #define O3V_ERR_LAUNCH (-3)
 
+// hipGetLastError() reports the last error of ANY earlier runtime call of this host thread (torch's own included),
+// so clear it right before our launch and read it right after.
+#define O3V_KLAUNCH(...)               \
+    do {                               \
+        (void)hipGetLastError();       \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define O3V_CHECK_LAUNCH()                                  \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

@@ -63,13 +63,13 @@ extern "C" int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, in
     if (cols > 16 * 512) return O3V_ERR_SHAPE;
     dim3 grid((rows + 3) / 4), block(256);
     if (cols <= 4 * 512)
-        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+        O3V_KLAUNCH(rmsnorm_kernel<4>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
                            rows, cols, ld_in, ld_out, eps);
     else if (cols <= 8 * 512)
-        hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+        O3V_KLAUNCH(rmsnorm_kernel<8>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
                            rows, cols, ld_in, ld_out, eps);
     else
-        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
+        O3V_KLAUNCH(rmsnorm_kernel<16>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out,
                            rows, cols, ld_in, ld_out, eps);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -125,7 +125,7 @@ extern "C" int o3v_vit_rope(void* qkv, const float* cosT, const float* sinT, int
     long total = (long)P * 2 * H * (D >> 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(vit_rope_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)qkv, cosT, sinT, P, H, D);
+    O3V_KLAUNCH(vit_rope_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)qkv, cosT, sinT, P, H, D);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }
@@ -158,7 +158,7 @@ extern "C" int o3v_mrope_table(const int* pos, const float* inv_freq, const int*
     long total = (long)T * (D >> 1);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mrope_table_kernel, dim3(blocks), dim3(256), 0, stream, pos, inv_freq, axis_of, (bf16_t*)cosT,
+    O3V_KLAUNCH(mrope_table_kernel, dim3(blocks), dim3(256), 0, stream, pos, inv_freq, axis_of, (bf16_t*)cosT,
                        (bf16_t*)sinT, T, D);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -239,7 +239,7 @@ extern "C" int o3v_qkv_rope_cache(const void* qkv, const void* cosT, const void*
     long total = (long)T * (Hq + 2 * Hkv) * (D >> 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(qkv_rope_cache_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
+    O3V_KLAUNCH(qkv_rope_cache_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
                        (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache, slot_base, T, tokens_per_row, Hq,
                        Hkv, D, Tmax, cs_stride_row, cs_off);
     O3V_CHECK_LAUNCH();
@@ -266,7 +266,7 @@ extern "C" int o3v_gather_rows(const void* src, const int* idx, void* dst, int r
     long total = (long)rows * (row_bytes >> 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, idx, (uint4*)dst, rows,
+    O3V_KLAUNCH(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, idx, (uint4*)dst, rows,
                        row_bytes >> 4);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -295,7 +295,7 @@ extern "C" int o3v_embed_scatter(const void* table, const void* vis, const int* 
     long total = (long)T * (hidden >> 3);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, (const uint4*)vis,
+    O3V_KLAUNCH(embed_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, (const uint4*)vis,
                        src_row, (uint4*)out, T, hidden >> 3);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -332,7 +332,7 @@ extern "C" int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0,
     long total = (long)P * (Kp >> 3);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, P, K0, Kp);
+    O3V_KLAUNCH(cast_pad_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, P, K0, Kp);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }
@@ -392,10 +392,10 @@ extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (is_u8)
-        hipLaunchKernelGGL(patchify_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
+        O3V_KLAUNCH(patchify_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
                            T, H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     else
-        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
+        O3V_KLAUNCH(patchify_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
                            H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -478,7 +478,7 @@ extern "C" int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, i
     if (!logits || !seen || !cur_tok || !finished || !out_ids || B < 0 || V <= 0 || step < 0 || step >= out_stride)
         return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
-    hipLaunchKernelGGL(sample_greedy_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
+    O3V_KLAUNCH(sample_greedy_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
                        finished, out_ids, margins, eos_ids, n_eos, pad_id, V, ldl, rep_penalty, step, out_stride);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -499,7 +499,7 @@ extern "C" int o3v_mark_seen(const int* ids, void* seen, int B, int S, int V, hi
     if (B * (long)S == 0) return O3V_OK;
     int blocks = (int)(((long)B * S + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(mark_seen_kernel, dim3(blocks), dim3(256), 0, stream, ids, (uint8_t*)seen, B, S, V);
+    O3V_KLAUNCH(mark_seen_kernel, dim3(blocks), dim3(256), 0, stream, ids, (uint8_t*)seen, B, S, V);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }
@@ -520,7 +520,7 @@ extern "C" int o3v_embed_tokens(const void* table, const int* tok, void* out, in
     if (B == 0) return O3V_OK;
     long total = (long)B * (hidden >> 3);
     int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, tok, (uint4*)out, B,
+    O3V_KLAUNCH(embed_tokens_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)table, tok, (uint4*)out, B,
                        hidden >> 3);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
@@ -559,7 +559,7 @@ extern "C" int o3v_logprob_gather(const void* logits, const int* target, float* 
                                   hipStream_t stream) {
     if (!logits || !target || !out || R < 0 || V <= 0) return O3V_ERR_ARG;
     if (R == 0) return O3V_OK;
-    hipLaunchKernelGGL(logprob_gather_kernel, dim3(R), dim3(256), 0, stream, (const bf16_t*)logits, target, out, V, ldl);
+    O3V_KLAUNCH(logprob_gather_kernel, dim3(R), dim3(256), 0, stream, (const bf16_t*)logits, target, out, V, ldl);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

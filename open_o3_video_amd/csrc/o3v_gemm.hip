@@ -259,7 +259,7 @@ int launch_gemv(const bf16_t* X, const bf16_t* W, const bf16_t* bias, const bf16
     const int waves = (outs + per_wave - 1) / per_wave;
     dim3 grid((waves + 3) / 4), block(256);
 #define O3V_GV(E) \
-    hipLaunchKernelGGL((gemv_bf16_kernel<M, R, E>), grid, block, 0, s, X, W, bias, res, out, N, K, ldx, ldw, ldo, ldr)
+    O3V_KLAUNCH((gemv_bf16_kernel<M, R, E>), grid, block, 0, s, X, W, bias, res, out, N, K, ldx, ldw, ldo, ldr)
     switch (epi) {
         case EPI_NONE: O3V_GV(EPI_NONE); break;
         case EPI_RESIDUAL: O3V_GV(EPI_RESIDUAL); break;
@@ -294,7 +294,7 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     dim3 grid(tiles_m * tiles_n), block(256);
     const size_t shmem = 4 * TILE_BYTES;
 #define O3V_GM(E)                                                                                                       \
-    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)W,            \
+    O3V_KLAUNCH((gemm_bf16_kernel<E>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)W,            \
                        (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, lda, ldw, ldo, ldr, tiles_m, tiles_n)
     switch (epilogue) {
         case EPI_NONE: O3V_GM(EPI_NONE); break;

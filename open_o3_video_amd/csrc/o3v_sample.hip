@@ -154,7 +154,7 @@ extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, in
         step >= out_stride || !(temperature > 0.f) || !(top_p > 0.f))
         return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
-    hipLaunchKernelGGL(sample_top_p_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
+    O3V_KLAUNCH(sample_top_p_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
                        finished, out_ids, chosen_logprob, eos_ids, n_eos, pad_id, V, ldl, rep_penalty, temperature,
                        top_p, seed, row_id, step, out_stride, scratch);
     O3V_CHECK_LAUNCH();

@@ -55,8 +55,8 @@ class O3VEngine:
         inv = 1.0 / (tc.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float) / D))
         self.inv_freq = inv.to(self.dev)
         self.axis_of = torch.from_numpy(indexing.mrope_axis_table(tc.mrope_section)).to(self.dev)
-        self.clip_mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.dev)
-        self.clip_std = torch.tensor(CLIP_STD, dtype=torch.float32, device=self.dev)
+        self.clip_mean = (C.c_float * 3)(*CLIP_MEAN)   # host arrays (read by the launcher, passed by value)
+        self.clip_std = (C.c_float * 3)(*CLIP_STD)
         self._vit_plan_cache = {}
 
     # ------------------------------------------------------------------------------------------ vision
@@ -108,8 +108,7 @@ class O3VEngine:
         fr = frames.to(self.dev).contiguous() if is_u8 else frames.to(self.dev, torch.float32).contiguous()
         P = T * (H // 14) * (W // 14)
         out = torch.empty((P, vc.patch_k_pad), dtype=torch.bfloat16, device=self.dev)
-        _lib.call("o3v_patchify", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, _ptr(self.clip_mean),
-                  _ptr(self.clip_std), _stream())
+        _lib.call("o3v_patchify", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, self.clip_mean, self.clip_std, _stream())
         grid = np.asarray([[1, H // 14, W // 14]] * T, dtype=np.int64)
         return out, grid
 

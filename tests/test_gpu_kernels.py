@@ -300,9 +300,9 @@ def test_patchify_matches_hf_processor(dev, golden_dir):
     import ctypes as C
     from open_o3_video_amd import _lib
     g = np.load(os.path.join(golden_dir, "g3_patchify.npz"))
-    mean = torch.tensor(g["mean"], dtype=torch.float32, device=dev)
-    std = torch.tensor(g["std"], dtype=torch.float32, device=dev)
-    P = lambda t: C.c_void_p(t.data_ptr())
+    mean = (C.c_float * 3)(*g["mean"].tolist())   # host arrays
+    std = (C.c_float * 3)(*g["std"].tolist())
+    P = lambda t: t if isinstance(t, C.Array) else C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for tag in "abc":
         fr = torch.from_numpy(g[f"{tag}_frames"])

@@ -15,7 +15,8 @@ import fixture_models as fm
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_ATOL = 0.12   # abs tolerance on logits of magnitude ~5-10 (bf16 has 8 bits of mantissa: ulp(8) = 0.0625)
+LOGIT_ATOL = 0.25   # abs tolerance on logits of magnitude ~8-16 (bf16 keeps 8 mantissa bits: ulp(16) = 0.125); HF's own
+                    # bf16 path is 0.12 away from its fp32 path on these fixtures
 VIT_RTOL = 0.03     # relative L2 error of the merged visual tokens vs HF fp32
 
 CASES = [("g6_tiny.npz", fm.tiny_config, 0, 16), ("g6_tiny_b.npz", fm.tiny_config, 1, 12),
