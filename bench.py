@@ -132,7 +132,8 @@ def kernel_roofline(eng, reps=3):
 
     def run():
         for l in range(L):
-            _lib.call("o3v_gemv_bf16", C.c_void_p(x.data_ptr()), C.c_void_p(eng.w.t[f"l{l}.gu_w"].data_ptr()), None, None,
+            _lib.call("o3v_gemv_norm_bf16", C.c_void_p(x.data_ptr()), C.c_void_p(eng.w.t[f"l{l}.ln2"].data_ptr()),
+                      float(tc.rms_norm_eps), C.c_void_p(eng.w.t[f"l{l}.gu_w"].data_ptr()), None, None,
                       C.c_void_p(out.data_ptr()), 1, 2 * I, H, H, H, I, 0, _lib.EPI_SWIGLU, st)
     run()
     torch.cuda.synchronize()
@@ -145,7 +146,7 @@ def kernel_roofline(eng, reps=3):
     avg_ms = e0.elapsed_time(e1) / (reps * L)
     bytes_per_launch = 2 * I * H * 2 + H * 2 + I * 2
     ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=4,SWIGLU> (LLM gate/up projection, decode)",
+    return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=4,KS=1,SWIGLU,NORM> (RMSNorm + LLM gate/up projection, decode)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
 

@@ -70,6 +70,12 @@ int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
 int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int ldx,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 
+/* RMSNorm (TF:65-79) fused into the projection that consumes it: out = epi(rmsnorm(X; norm_w, eps) . W^T + bias), M <= 8.
+ * Removes one launch per q/k/v, gate/up and lm_head projection of a decode step. */
+int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void* W, const void* bias, const void* res,
+                       void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
+                       o3v_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------------------------- */
 /* tiles: int32[n_tiles][8] = {q_row0, q_rows, k_row0, k_len, causal_off, k_lo, batch, 0}.
  * ViT varlen attention (TF:248-287) and causal GQA prefill attention (TF:186-208, :602-689). */
@@ -86,7 +92,7 @@ int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, fl
  * TF:generation/utils.py:2894-2929, TF:generation/logits_process.py:404-414 */
 int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
                       const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
-                      int out_stride, o3v_stream_t stream);
+                      int out_stride, float* scratch /* f32[B*256] */, o3v_stream_t stream);
 /* temperature + top-p + multinomial (TF:logits_process.py:301-303, :527-539; utils.py:2921-2923), counter-based RNG
  * keyed by (seed, row_id[b], step) so a completion does not depend on which rank/batch slot produced it */
 int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* chosen_logprob,
@@ -167,7 +173,7 @@ typedef struct {
     const int *k_lo;             /* [B] left-pad counts or NULL */
     const int *row_id;           /* [B] global completion index for the RNG or NULL */
     float *part_o, *part_ml;     /* decode-attention split buffers */
-    float *sample_scratch;       /* f32 [B,vocab] (sampling only) */
+    float *sample_scratch;       /* f32 [B,vocab] when sampling, f32 [B,256] for greedy */
     void *workspace; size_t ws_bytes;
 } o3v_decode_state;
 

@@ -239,36 +239,45 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const bf16_t* Kb = Kc + (size_t)b * k_bs + (size_t)hk * k_hs;
     const bf16_t* Vb = Vc + (size_t)b * k_bs + (size_t)hk * k_hs;
 
-    for (int kbase = k0 + wave * KPW; kbase < k1; kbase += 4 * KPW) {
-        const int key = kbase + slot;
-        const bool valid = key < k1 && key >= k_lo;
-        const int kl = key < ctx ? key : ctx - 1;
-        const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)kl * D + part * 8);
-        const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)kl * D + part * 8);
-        float kf[8], vf[8];
+    constexpr int U = 4;  // K/V loads of U iterations in flight before the first use
+    for (int kb0 = k0 + wave * KPW; kb0 < k1; kb0 += 4 * KPW * U) {
+        u32x4 kv[U], vv[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kf[2 * j] = bf_lo(kv[j]);
-            kf[2 * j + 1] = bf_hi(kv[j]);
-            vf[2 * j] = bf_lo(vv[j]);
-            vf[2 * j + 1] = bf_hi(vv[j]);
+        for (int u = 0; u < U; ++u) {
+            const int key = kb0 + u * 4 * KPW + slot;
+            const int kl = key < ctx ? key : ctx - 1;
+            kv[u] = *reinterpret_cast<const u32x4*>(Kb + (size_t)kl * D + part * 8);
+            vv[u] = *reinterpret_cast<const u32x4*>(Vb + (size_t)kl * D + part * 8);
         }
 #pragma unroll
-        for (int r = 0; r < NREP_MAX; ++r) {
-            float s = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int key = kb0 + u * 4 * KPW + slot;
+            const bool valid = key < k1 && key >= k_lo;
+            float kf[8], vf[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf(q[r][j], kf[j], s);
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bf_lo(kv[u][j]);
+                kf[2 * j + 1] = bf_hi(kv[u][j]);
+                vf[2 * j] = bf_lo(vv[u][j]);
+                vf[2 * j + 1] = bf_hi(vv[u][j]);
+            }
 #pragma unroll
-            for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            s = valid ? s : -1e30f;
-            const float mn = fmaxf(m[r], s);
-            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
-            float p = valid ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
-            p = bf2f(f2bf(p));  // the reference rounds the probabilities to bf16 before P.V
-            m[r] = mn;
-            l[r] = l[r] * alpha + p;
+            for (int r = 0; r < NREP_MAX; ++r) {
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
+                for (int j = 0; j < 8; ++j) s = fmaf(q[r][j], kf[j], s);
+#pragma unroll
+                for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                s = valid ? s : -1e30f;
+                const float mn = fmaxf(m[r], s);
+                const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+                float p = valid ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
+                p = bf2f(f2bf(p));  // the reference rounds the probabilities to bf16 before P.V
+                m[r] = mn;
+                l[r] = l[r] * alpha + p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
+            }
         }
     }
     // ---- merge the KPW slot streams of this wave (lanes with equal `part`)
@@ -318,22 +327,32 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
+// Merge the context splits: block per (b, head); split weights are computed once into LDS, then every thread sums its
+// output dimension over the splits with independent loads.
 template <int D>
-__global__ void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                           bf16_t* __restrict__ out, int nsplit) {
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+                                                                  const float* __restrict__ part_ml,
+                                                                  bf16_t* __restrict__ out, int nsplit) {
+    __shared__ float sw[64];
+    __shared__ float s_inv;
     const int bh = blockIdx.x;  // b*Hq + h
-    const int d = threadIdx.x;
-    if (d >= D) return;
-    float mn = -1e30f;
-    for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, part_ml[((size_t)bh * nsplit + s) * 2]);
-    float acc = 0.f, lt = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const size_t idx = (size_t)bh * nsplit + s;
-        const float sc = __builtin_amdgcn_exp2f(part_ml[idx * 2] - mn);
-        acc += part_o[idx * D + d] * sc;
-        lt += part_ml[idx * 2 + 1] * sc;
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const float mv = t < nsplit ? part_ml[((size_t)bh * nsplit + t) * 2] : -1e30f;
+        const float lv = t < nsplit ? part_ml[((size_t)bh * nsplit + t) * 2 + 1] : 0.f;
+        const float mn = wave_max(mv);
+        const float w = t < nsplit ? __builtin_amdgcn_exp2f(mv - mn) : 0.f;
+        const float lt = wave_sum(lv * w);
+        sw[t] = w;
+        if (t == 0) s_inv = lt > 0.f ? 1.0f / lt : 0.f;
     }
-    out[(size_t)bh * D + d] = f2bf(lt > 0.f ? acc / lt : 0.f);
+    __syncthreads();
+    if (t >= D) return;
+    const float* po = part_o + (size_t)bh * nsplit * D + t;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < nsplit; ++s) acc = fmaf(po[(size_t)s * D], sw[s], acc);
+    out[(size_t)bh * D + t] = f2bf(acc * s_inv);
 }
 
 }  // namespace
@@ -366,7 +385,7 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
                                const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
                                hipStream_t stream) {
     if (!Q || !Kc || !Vc || !out || !part_o || !part_ml || B < 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || ctx <= 0 ||
-        ctx > Tmax || nsplit <= 0)
+        ctx > Tmax || nsplit <= 0 || nsplit > 64)
         return O3V_ERR_ARG;
     const int n_rep = Hq / Hkv;
     if (n_rep > NREP_MAX) return O3V_ERR_SHAPE;
@@ -377,7 +396,7 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
 #define O3V_AD(DD)                                                                                                     \
     O3V_KLAUNCH((attn_decode_kernel<DD>), grid, block, 0, stream, (const bf16_t*)Q, (const bf16_t*)Kc,           \
                        (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2);                \
-    O3V_KLAUNCH((attn_decode_combine_kernel<DD>), dim3(B* Hq), dim3(DD < 64 ? 64 : DD), 0, stream, part_o,      \
+    O3V_KLAUNCH((attn_decode_combine_kernel<DD>), dim3(B* Hq), dim3(128), 0, stream, part_o,      \
                        part_ml, (bf16_t*)out, nsplit)
     switch (D) {
         case 32: O3V_AD(32); break;

@@ -407,17 +407,31 @@ extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int
 // byte map [B,V]), argmax with lowest-index tie break, pad after EOS, margin = top1 - top2.
 // One 1024-thread block per sequence.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sample_greedy_kernel(const bf16_t* __restrict__ logits, uint8_t* __restrict__ seen,
-                                                             int* __restrict__ cur_tok, int* __restrict__ finished,
-                                                             int* __restrict__ out_ids, float* __restrict__ margins,
-                                                             const int* __restrict__ eos_ids, int n_eos, int pad_id,
-                                                             int V, int ldl, float rep_penalty, int step, int out_stride) {
-    const int b = blockIdx.x;
+constexpr int GREEDY_NB = 64;
+
+__device__ __forceinline__ void top2_merge(float& best, int& bi, float& second, float ob, int oi, float os) {
+    if (ob > best || (ob == best && oi < bi)) {
+        second = fmaxf(best, os);
+        best = ob;
+        bi = oi;
+    } else {
+        second = fmaxf(second, ob);
+    }
+}
+
+// stage 1: grid (NB, B) x 256 threads, each block reduces a contiguous slice of the vocabulary to (best, idx, second)
+__global__ __launch_bounds__(256) void sample_greedy_partial_kernel(const bf16_t* __restrict__ logits,
+                                                                    const uint8_t* __restrict__ seen,
+                                                                    float* __restrict__ part, int V, int ldl,
+                                                                    float rep_penalty) {
+    const int b = blockIdx.y, nb = blockIdx.x;
     const bf16_t* lr = logits + (size_t)b * ldl;
-    uint8_t* sr = seen + (size_t)b * V;
+    const uint8_t* sr = seen + (size_t)b * V;
+    const int per = (V + GREEDY_NB - 1) / GREEDY_NB;
+    const int i0 = nb * per, i1 = (i0 + per < V) ? i0 + per : V;
     float best = -INFINITY, second = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
         float s = bf2f(lr[i]);
         if (rep_penalty != 1.0f && sr[i]) s = (s < 0.f) ? s * rep_penalty : s / rep_penalty;
         if (s > best) {
@@ -428,58 +442,76 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const bf16_t* __res
             second = s;
         }
     }
-    // wave reduce (value desc, index asc)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
-        int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-            second = fmaxf(best, os);
-            best = ob;
-            bi = oi;
-        } else {
-            second = fmaxf(second, ob);
-        }
+        const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        top2_merge(best, bi, second, ob, oi, os);
     }
-    __shared__ float sb[16], ss[16];
-    __shared__ int si[16];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
+    __shared__ float sb[4], ss[4];
+    __shared__ int si[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
         sb[w] = best;
         ss[w] = second;
         si[w] = bi;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
-            if (sb[k] > best || (sb[k] == best && si[k] < bi)) {
-                second = fmaxf(best, ss[k]);
-                best = sb[k];
-                bi = si[k];
-            } else {
-                second = fmaxf(second, sb[k]);
-            }
-        }
+        for (int k = 1; k < 4; ++k) top2_merge(best, bi, second, sb[k], si[k], ss[k]);
+        float* p = part + ((size_t)b * GREEDY_NB + nb) * 4;
+        p[0] = best;
+        p[1] = __int_as_float(bi);
+        p[2] = second;
+    }
+}
+
+// stage 2: one wave per sequence merges the NB partials and applies the token bookkeeping
+__global__ __launch_bounds__(64) void sample_greedy_final_kernel(const float* __restrict__ part, uint8_t* __restrict__ seen,
+                                                                 int* __restrict__ cur_tok, int* __restrict__ finished,
+                                                                 int* __restrict__ out_ids, float* __restrict__ margins,
+                                                                 const int* __restrict__ eos_ids, int n_eos, int pad_id,
+                                                                 int V, int step, int out_stride) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* p = part + ((size_t)b * GREEDY_NB + lane) * 4;
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0x7fffffff;
+    if (lane < GREEDY_NB) {
+        best = p[0];
+        bi = __float_as_int(p[1]);
+        second = p[2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        top2_merge(best, bi, second, ob, oi, os);
+    }
+    if (lane == 0) {
         int tok = finished[b] ? pad_id : bi;
         if (!finished[b]) {
             for (int k = 0; k < n_eos; ++k)
                 if (tok == eos_ids[k]) finished[b] = 1;
         }
-        if (tok >= 0 && tok < V) sr[tok] = 1;
+        if (tok >= 0 && tok < V) seen[(size_t)b * V + tok] = 1;
         cur_tok[b] = tok;
         out_ids[(size_t)b * out_stride + step] = tok;
         if (margins) margins[(size_t)b * out_stride + step] = best - second;
     }
 }
 
+// scratch: f32 [B, 64, 4] partials
 extern "C" int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
                                  const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty,
-                                 int step, int out_stride, hipStream_t stream) {
-    if (!logits || !seen || !cur_tok || !finished || !out_ids || B < 0 || V <= 0 || step < 0 || step >= out_stride)
+                                 int step, int out_stride, float* scratch, hipStream_t stream) {
+    if (!logits || !seen || !cur_tok || !finished || !out_ids || !scratch || B < 0 || V <= 0 || step < 0 ||
+        step >= out_stride)
         return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
-    O3V_KLAUNCH(sample_greedy_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
-                       finished, out_ids, margins, eos_ids, n_eos, pad_id, V, ldl, rep_penalty, step, out_stride);
+    O3V_KLAUNCH(sample_greedy_partial_kernel, dim3(GREEDY_NB, B), dim3(256), 0, stream, (const bf16_t*)logits,
+                (const uint8_t*)seen, scratch, V, ldl, rep_penalty);
+    O3V_KLAUNCH(sample_greedy_final_kernel, dim3(B), dim3(64), 0, stream, scratch, (uint8_t*)seen, cur_tok, finished, out_ids,
+                margins, eos_ids, n_eos, pad_id, V, step, out_stride);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

@@ -164,6 +164,9 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
                             o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
+    if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
+        return o3v_gemv_norm_bf16(x, d->final_norm, d->rms_eps, d->lm_head, nullptr, nullptr, logits, rows, d->vocab, H, ldx, H,
+                                  d->vocab, 0, O3V_EPI_NONE, s);
     TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
     for (int r0 = 0; r0 < rows;) {
         // GEMV groups of <= 8 rows for small row counts; one MFMA GEMM otherwise
@@ -183,7 +186,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     const int B = st->B;
     if (B <= 0 || B > 8 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew || st->S + st->Tnew > st->Tmax + 1)
         return O3V_ERR_ARG;
-    if (st->do_sample && !st->sample_scratch) return O3V_ERR_ARG;
+    if (!st->sample_scratch) return O3V_ERR_ARG;
     const int H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter, V = d->vocab;
     const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
     LlmWs w;
@@ -199,7 +202,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                  st->row_id, step, st->Tnew, st->sample_scratch, s));
         else
             TRY(o3v_sample_greedy(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
-                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, s));
+                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, st->sample_scratch, s));
         if (skip_last_forward && i == n_steps - 1) break;
         if (st->S + step >= st->Tmax) return O3V_ERR_ARG;
         // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
@@ -208,15 +211,15 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
-            TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
-            TRY(o3v_gemv_bf16(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, H, NQKV, 0, O3V_EPI_NONE, s));
+            TRY(o3v_gemv_norm_bf16(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, H, NQKV, 0,
+                                   O3V_EPI_NONE, s));
             TRY(o3v_qkv_rope_cache(w.qkv, st->cosT, st->sinT, w.q, kc, vc, st->S + step, B, 1, Hq, Hkv, D, st->Tmax, st->Tnew,
                                    step, s));
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
                                 st->Tmax, st->nsplit, scale, s));
             TRY(o3v_gemv_bf16(w.att, lw.o_w, nullptr, st->x, st->x, B, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
-            TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
-            TRY(o3v_gemv_bf16(w.h, lw.gu_w, nullptr, nullptr, w.mlp, B, 2 * I, H, H, H, I, 0, O3V_EPI_SWIGLU, s));
+            TRY(o3v_gemv_norm_bf16(st->x, lw.ln2, d->rms_eps, lw.gu_w, nullptr, nullptr, w.mlp, B, 2 * I, H, H, H, I, 0,
+                                   O3V_EPI_SWIGLU, s));
             TRY(o3v_gemv_bf16(w.mlp, lw.down_w, nullptr, st->x, st->x, B, H, I, I, I, H, H, O3V_EPI_RESIDUAL, s));
         }
         TRY(o3v_llm_head(d, st->x, H, B, w.normed, st->logits, s));

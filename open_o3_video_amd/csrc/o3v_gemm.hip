@@ -154,10 +154,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small-M weight-streaming GEMV: each wave owns R weight rows, walks K with 16-byte loads (64 lanes x
-// 8 bf16 = 512 k per step), keeps M x-chunks and R w-chunks in flight, reduces across the wave once at
-// the end.  x[M,K] is tiny and shared by every wave: it is read through L1/L2, the weights stream
-// from HBM exactly once.  M is a template parameter so the accumulators stay in registers.
+// Small-M weight-streaming GEMV (decode).  Block = 4 waves arranged as (4/KS) row groups x KS K-slices:
+// a wave owns R weight rows over its K-slice, walks it with 16-byte non-temporal loads (64 lanes x 8 bf16
+// = 512 k per step, U steps in flight), fp32 FMA, one wave reduction, K-slices summed through LDS.
+//   * x[M,K] is tiny and shared by every wave: read through L1/L2, or -- NORM variant -- normalised once per
+//     block into LDS: the RMSNorm that precedes every q/k/v and gate/up projection (TF:65-79, :733-748) is
+//     fused here with its two bf16 rounding points, which removes one launch per projection.
+//   * the weights stream from HBM exactly once.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fma8(const u32x4& w, const u32x4& x, float& acc) {
 #pragma unroll
@@ -167,34 +170,78 @@ __device__ __forceinline__ void fma8(const u32x4& w, const u32x4& x, float& acc)
     }
 }
 
-template <int M, int R, int EPI>
+template <int M, int R, int KS, int EPI, bool NORM>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                        bf16_t* __restrict__ out, int N, int K, int ldx, int ldw, int ldo,
-                                                        int ldr) {
-    const int lane = threadIdx.x & 63;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // SWIGLU: a wave owns R/2 output columns = R/2 (gate,up) row pairs of the 16-row-interleaved weight
+                                                        bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
+                                                        float eps, int N, int K, int ldx, int ldw, int ldo, int ldr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M*K bf16] [KS>1: 4*R*M f32]
+    constexpr int RG = 4 / KS;                                   // row groups per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = wave / KS, ks = wave % KS;
+    const int nch = K >> 3;
+
+    if (NORM) {
+        // ---- block-wide RMSNorm of x into LDS: xs[m][k] = bf16(w[k] * bf16(x[m][k] * rstd[m]))
+        float ss[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) ss[m] = 0.f;
+        for (int c = threadIdx.x; c < nch; c += 256) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ss[m] = fmaf(bf_lo(v[j]), bf_lo(v[j]), ss[m]);
+                    ss[m] = fmaf(bf_hi(v[j]), bf_hi(v[j]), ss[m]);
+                }
+            }
+        }
+        float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 4 * R * M * 4);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            ss[m] = wave_sum(ss[m]);
+            if (lane == 0) red[wave * M + m] = ss[m];
+        }
+        __syncthreads();
+        float rstd[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            rstd[m] = 1.0f / sqrtf((red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m]) / (float)K + eps);
+        for (int c = threadIdx.x; c < nch; c += 256) {
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = pack_bf2(bf_lo(wv[j]) * rbf(bf_lo(v[j]) * rstd[m]), bf_hi(wv[j]) * rbf(bf_hi(v[j]) * rstd[m]));
+                *reinterpret_cast<u32x4*>(smem + ((size_t)m * K + (size_t)c * 8) * 2) = o;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- rows of this wave.  SWIGLU: R/2 output columns = R/2 (gate,up) row pairs of the 16-row-interleaved weight
+    const int grp = blockIdx.x * RG + rg;
     int rows[R];
-    const int first = wave_g * R;
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
-            const int no = wave_g * (R / 2) + r;  // output column
+            const int no = grp * (R / 2) + r;
             const int g = (no >> 4) * 32 + (no & 15);
             rows[2 * r] = g;
             rows[2 * r + 1] = g + 16;
         }
-        if (wave_g * (R / 2) >= (N >> 1)) return;
     } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) rows[r] = first + r;
-        if (first >= N) return;
+        for (int r = 0; r < R; ++r) rows[r] = grp * R + r;
     }
     const u32x4* wp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int rr = rows[r] < N ? rows[r] : N - 1;
+        const int rr = rows[r] < N ? rows[r] : N - 1;  // tail rows re-read a valid row, never stored
         wp[r] = reinterpret_cast<const u32x4*>(W + (size_t)rr * ldw);
     }
     float acc[R][M];
@@ -203,28 +250,67 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 
-    const int nch = K >> 3;
-    for (int c = lane; c < nch; c += 64) {
-        u32x4 wv[R], xv[M];
+    // K-slice in whole 64-chunk steps
+    const int steps = (nch + 63) >> 6;
+    const int sps = (steps + KS - 1) / KS;
+    const int c_begin = ks * sps * 64;
+    int c_end = c_begin + sps * 64;
+    c_end = c_end < nch ? c_end : nch;
+    constexpr int U = (R >= 4) ? 2 : 4;
+    for (int c0 = c_begin; c0 < c_end; c0 += 64 * U) {
+        u32x4 wv[U][R], xv[U][M];
 #pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load(wp[r] + c);
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const bool in = c < c_end;
+            const int cc = in ? c : c_begin;
 #pragma unroll
-        for (int m = 0; m < M; ++m) xv[m] = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+            for (int r = 0; r < R; ++r) {
+                wv[u][r] = __builtin_nontemporal_load(wp[r] + cc);
+                if (!in) wv[u][r] = (u32x4){0, 0, 0, 0};
+            }
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+            for (int m = 0; m < M; ++m)
+                xv[u][m] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + (size_t)cc * 8) * 2)
+                                : *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
+        }
 #pragma unroll
-            for (int m = 0; m < M; ++m) fma8(wv[r], xv[m], acc[r][m]);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < M; ++m) fma8(wv[u][r], xv[u][m], acc[r][m]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
 
+    if (KS > 1) {
+        float* part = reinterpret_cast<float*>(smem + (NORM ? (size_t)M * K * 2 : 0));
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < M; ++m) part[(wave * R + r) * M + m] = acc[r][m];
+        }
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float t = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < KS; ++k2) t += part[((rg * KS + k2) * R + r) * M + m];
+                acc[r][m] = t;
+            }
+    }
     if (lane != 0) return;
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
-            const int no = wave_g * (R / 2) + r;
+            const int no = grp * (R / 2) + r;
             if (no >= (N >> 1)) continue;
             const float bg = bias ? bf2f(bias[rows[2 * r]]) : 0.f;
             const float bu = bias ? bf2f(bias[rows[2 * r + 1]]) : 0.f;
@@ -251,16 +337,26 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     }
 }
 
-template <int M, int R>
-int launch_gemv(const bf16_t* X, const bf16_t* W, const bf16_t* bias, const bf16_t* res, bf16_t* out, int N, int K, int ldx,
-                int ldw, int ldo, int ldr, int epi, hipStream_t s) {
-    const int per_wave = (epi == EPI_SWIGLU) ? R / 2 : R;
-    const int outs = (epi == EPI_SWIGLU) ? N / 2 : N;
-    const int waves = (outs + per_wave - 1) / per_wave;
-    dim3 grid((waves + 3) / 4), block(256);
-#define O3V_GV(E) \
-    O3V_KLAUNCH((gemv_bf16_kernel<M, R, E>), grid, block, 0, s, X, W, bias, res, out, N, K, ldx, ldw, ldo, ldr)
-    switch (epi) {
+struct GemvArgs {
+    const bf16_t *X, *W, *bias, *res, *norm_w;
+    bf16_t* out;
+    float eps;
+    int N, K, ldx, ldw, ldo, ldr, epi;
+    hipStream_t s;
+};
+
+template <int M, int R, int KS, bool NORM>
+int launch_gemv(const GemvArgs& a) {
+    const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : R;
+    const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
+    const int per_block = per_wave * (4 / KS);
+    dim3 grid((outs + per_block - 1) / per_block), block(256);
+    const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)4 * R * M * 4 + (NORM ? 4 * M * 4 : 0);
+    if (shmem > 160 * 1024) return O3V_ERR_SHAPE;
+#define O3V_GV(E)                                                                                                         \
+    O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,  \
+                a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr)
+    switch (a.epi) {
         case EPI_NONE: O3V_GV(EPI_NONE); break;
         case EPI_RESIDUAL: O3V_GV(EPI_RESIDUAL); break;
         case EPI_GELU: O3V_GV(EPI_GELU); break;
@@ -271,14 +367,19 @@ int launch_gemv(const bf16_t* X, const bf16_t* W, const bf16_t* bias, const bf16
     return O3V_OK;
 }
 
-template <int M>
-int launch_gemv_m(const bf16_t* X, const bf16_t* W, const bf16_t* bias, const bf16_t* res, bf16_t* out, int N, int K,
-                  int ldx, int ldw, int ldo, int ldr, int epi, hipStream_t s) {
-    // rows per wave: 4 when that still gives >= 2 waves per SIMD chip-wide, else 2 (small N such as o_proj)
-    const int outs = (epi == EPI_SWIGLU) ? N / 2 : N;
-    if (M <= 2 && outs >= 4 * 2048 * (epi == EPI_SWIGLU ? 2 : 1))
-        return launch_gemv<M, 4>(X, W, bias, res, out, N, K, ldx, ldw, ldo, ldr, epi, s);
-    return launch_gemv<M, 2>(X, W, bias, res, out, N, K, ldx, ldw, ldo, ldr, epi, s);
+template <int M, bool NORM>
+int launch_gemv_m(const GemvArgs& a) {
+    // Decomposition: enough waves to keep >= 32 KiB of weight loads in flight per CU, whole 512-k steps per wave.
+    const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
+    const int steps = (a.K / 8 + 63) / 64;
+    if (a.epi == EPI_SWIGLU) {
+        if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM>(a);  // 2 (gate,up) pairs per wave
+        return launch_gemv<M, 2, 1, NORM>(a);
+    }
+    if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM>(a);     // lm_head
+    if (steps >= 16) return launch_gemv<M, 2, 4, NORM>(a);                 // long K (down_proj): split K over the 4 waves
+    if (steps >= 6 && outs <= 8192) return launch_gemv<M, 2, 2, NORM>(a);  // o_proj / qkv
+    return launch_gemv<M, 2, 1, NORM>(a);
 }
 
 }  // namespace
@@ -308,27 +409,43 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     return O3V_OK;
 }
 
-extern "C" int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
-                             int ldx, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {
+static int gemv_dispatch(const void* X, const void* W, const void* bias, const void* res, void* out, const void* norm_w,
+                         float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
+                         hipStream_t stream) {
     if (!X || !W || !out || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 8) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
-    const bf16_t *x = (const bf16_t*)X, *w = (const bf16_t*)W, *b = (const bf16_t*)bias, *r = (const bf16_t*)res;
-    bf16_t* o = (bf16_t*)out;
+    GemvArgs a{(const bf16_t*)X, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w,
+               (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream};
     int rc;
+#define O3V_M(MM) rc = norm_w ? launch_gemv_m<MM, true>(a) : launch_gemv_m<MM, false>(a)
     switch (M) {
-        case 1: rc = launch_gemv_m<1>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 2: rc = launch_gemv_m<2>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 3: rc = launch_gemv_m<3>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 4: rc = launch_gemv_m<4>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 5: rc = launch_gemv_m<5>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 6: rc = launch_gemv_m<6>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        case 7: rc = launch_gemv_m<7>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
-        default: rc = launch_gemv_m<8>(x, w, b, r, o, N, K, ldx, ldw, ldo, ldr, epilogue, stream); break;
+        case 1: O3V_M(1); break;
+        case 2: O3V_M(2); break;
+        case 3: O3V_M(3); break;
+        case 4: O3V_M(4); break;
+        case 5: O3V_M(5); break;
+        case 6: O3V_M(6); break;
+        case 7: O3V_M(7); break;
+        default: O3V_M(8); break;
     }
+#undef O3V_M
     if (rc != O3V_OK) return rc;
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
+                             int ldx, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {
+    return gemv_dispatch(X, W, bias, res, out, nullptr, 0.f, M, N, K, ldx, ldw, ldo, ldr, epilogue, stream);
+}
+
+// RMSNorm fused into the projection: out = epi(rmsnorm(X; norm_w, eps) . W^T + bias)   (TF:65-79 + nn.Linear)
+extern "C" int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void* W, const void* bias,
+                                  const void* res, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
+                                  int epilogue, hipStream_t stream) {
+    if (!norm_w) return O3V_ERR_ARG;
+    return gemv_dispatch(X, W, bias, res, out, norm_w, eps, M, N, K, ldx, ldw, ldo, ldr, epilogue, stream);
 }

@@ -266,7 +266,7 @@ class O3VEngine:
         nsplit = max(1, min(64, (Tmax + 63) // 64, max(1, 1024 // max(1, B * tc.num_key_value_heads))))
         part_o = torch.empty(n_rep_total * nsplit * tc.head_dim, dtype=torch.float32, device=self.dev)
         part_ml = torch.empty(n_rep_total * nsplit * 2, dtype=torch.float32, device=self.dev)
-        scratch = torch.empty((B, V), dtype=torch.float32, device=self.dev) if do_sample else None
+        scratch = torch.empty((B, V if do_sample else 256), dtype=torch.float32, device=self.dev)
         xdec = torch.empty((B, H), dtype=torch.bfloat16, device=self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
@@ -278,7 +278,7 @@ class O3VEngine:
                               out_ids=out_ids.data_ptr(), margins=0 if margins is None else margins.data_ptr(),
                               eos_ids=eos.data_ptr(), k_lo=k_lo.data_ptr(), row_id=rid.data_ptr(),
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
-                              sample_scratch=0 if scratch is None else scratch.data_ptr(), workspace=ws.data_ptr(),
+                              sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
                               ws_bytes=nbytes)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0

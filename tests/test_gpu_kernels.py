@@ -131,6 +131,30 @@ def test_gemv(dev, M, N, K):
         close_bf16(out, _epi_ref(acc, b, r, epi))
 
 
+@pytest.mark.parametrize("M", [1, 2, 4, 8])
+@pytest.mark.parametrize("N,K,epi_name", [(4608, 3584, "none"), (37888, 3584, "swiglu"), (152064, 3584, "none"),
+                                          (512, 128, "none"), (2304, 896, "swiglu")])
+def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
+    """RMSNorm fused into the decode projections must equal rmsnorm kernel -> gemv (same rounding points)."""
+    import ctypes as C
+    from open_o3_video_amd import ops, _lib
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 2).to(BF)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    epi = ops.EPI_SWIGLU if epi_name == "swiglu" else ops.EPI_NONE
+    xn = model_ref.rmsnorm(x, nw, 1e-6).to(dev)
+    ref = ops.gemm(xn, w, bias, None, epi, force="gemv")
+    out = torch.empty_like(ref)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    xd, nd = x.to(dev), nw.to(dev)
+    _lib.call("o3v_gemv_norm_bf16", P(xd), P(nd), 1e-6, P(w), P(bias), None, P(out), M, N, K, K, K, out.stride(0), 0, epi,
+              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    close_bf16(out, ref, ulps=1, atol=1e-3, frac=0.9995)
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from open_o3_video_amd import ops, _lib
     a = torch.zeros(4, 100, dtype=BF, device=dev)
@@ -357,7 +381,9 @@ def test_sample_greedy_and_logprob(dev):
         out = torch.full((B, T), -1, dtype=torch.int32, device=dev)
         mar = torch.zeros(B, T, device=dev)
         eos = torch.tensor([V + 5], dtype=torch.int32, device=dev)
-        _lib.call("o3v_sample_greedy", P(ld), P(seen), P(cur), P(fin), P(out), P(mar), P(eos), 1, 777, B, V, V, pen, 2, T, st)
+        scr = torch.empty(B, 256, device=dev)
+        _lib.call("o3v_sample_greedy", P(ld), P(seen), P(cur), P(fin), P(out), P(mar), P(eos), 1, 777, B, V, V, pen, 2, T,
+                  P(scr), st)
         sc = model_ref.repetition_penalty(logits.float(), ids, pen) if pen != 1.0 else logits.float()
         top2 = sc.topk(2, dim=-1)
         exp = top2.indices[:, 0].clone()
