@@ -76,6 +76,12 @@ int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void*
                        void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
                        o3v_stream_t stream);
 
+/* Decode q/k/v projection fully fused: RMSNorm -> Linear(+bias) -> M-RoPE -> q to qout[M,Hq,D], k,v appended to the
+ * cache [M,Hkv,Tmax,D] at `slot` (TF:733-736, :636-664); cos/sin row of sequence m = m*cs_stride_row + cs_off. */
+int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* bias, int M, int K,
+                           int ldx, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache, int slot,
+                           int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------------------------- */
 /* tiles: int32[n_tiles][8] = {q_row0, q_rows, k_row0, k_len, causal_off, k_lo, batch, 0}.
  * ViT varlen attention (TF:248-287) and causal GQA prefill attention (TF:186-208, :602-689). */

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int k_lo = k_lo_arr ? k_lo_arr[b] : 0;
 
     int chunk = (ctx + nsplit - 1) / nsplit;
-    chunk = (chunk + 4 * KPW - 1) / (4 * KPW) * (4 * KPW);
+    chunk = (chunk + 16 * KPW - 1) / (16 * KPW) * (16 * KPW);  // whole trips: 4 waves x KPW slots x U keys
     const int k0 = split * chunk;
     int k1 = k0 + chunk;
     k1 = k1 < ctx ? k1 : ctx;
@@ -239,44 +239,58 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const bf16_t* Kb = Kc + (size_t)b * k_bs + (size_t)hk * k_hs;
     const bf16_t* Vb = Vc + (size_t)b * k_bs + (size_t)hk * k_hs;
 
-    constexpr int U = 4;  // K/V loads of U iterations in flight before the first use
+    // U keys per lane group and trip: all K/V loads of a trip are in flight before the first use, and the online
+    // softmax rescales once per trip (max over the U scores), not once per key.
+    constexpr int U = 4;
     for (int kb0 = k0 + wave * KPW; kb0 < k1; kb0 += 4 * KPW * U) {
         u32x4 kv[U], vv[U];
+        bool valid[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = kb0 + u * 4 * KPW + slot;
+            valid[u] = key < k1 && key >= k_lo;
             const int kl = key < ctx ? key : ctx - 1;
             kv[u] = *reinterpret_cast<const u32x4*>(Kb + (size_t)kl * D + part * 8);
             vv[u] = *reinterpret_cast<const u32x4*>(Vb + (size_t)kl * D + part * 8);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int key = kb0 + u * 4 * KPW + slot;
-            const bool valid = key < k1 && key >= k_lo;
-            float kf[8], vf[8];
+        for (int r = 0; r < NREP_MAX; ++r) {
+            if (r >= n_rep) break;  // wave-uniform
+            float sc[U];
+            float mn = m[r];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bf_lo(kv[u][j]);
-                kf[2 * j + 1] = bf_hi(kv[u][j]);
-                vf[2 * j] = bf_lo(vv[u][j]);
-                vf[2 * j + 1] = bf_hi(vv[u][j]);
-            }
-#pragma unroll
-            for (int r = 0; r < NREP_MAX; ++r) {
+            for (int u = 0; u < U; ++u) {
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(q[r][j], kf[j], s);
+                for (int j = 0; j < 4; ++j) {
+                    s = fmaf(q[r][2 * j], bf_lo(kv[u][j]), s);
+                    s = fmaf(q[r][2 * j + 1], bf_hi(kv[u][j]), s);
+                }
 #pragma unroll
                 for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                s = valid ? s : -1e30f;
-                const float mn = fmaxf(m[r], s);
-                const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
-                float p = valid ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
-                p = bf2f(f2bf(p));  // the reference rounds the probabilities to bf16 before P.V
-                m[r] = mn;
-                l[r] = l[r] * alpha + p;
+                sc[u] = valid[u] ? s : -1e30f;
+                mn = fmaxf(mn, sc[u]);
+            }
+            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+            m[r] = mn;
+            float pu[U], ps = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
+            for (int u = 0; u < U; ++u) {
+                const float p = valid[u] ? __builtin_amdgcn_exp2f(sc[u] - mn) : 0.f;
+                pu[u] = bf2f(f2bf(p));  // the reference rounds the probabilities to bf16 before P.V
+                ps += pu[u];
+            }
+            l[r] = l[r] * alpha + ps;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a0 = o[r][2 * j] * alpha, a1 = o[r][2 * j + 1] * alpha;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    a0 = fmaf(pu[u], bf_lo(vv[u][j]), a0);
+                    a1 = fmaf(pu[u], bf_hi(vv[u][j]), a1);
+                }
+                o[r][2 * j] = a0;
+                o[r][2 * j + 1] = a1;
             }
         }
     }

@@ -211,10 +211,8 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
-            TRY(o3v_gemv_norm_bf16(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, H, NQKV, 0,
-                                   O3V_EPI_NONE, s));
-            TRY(o3v_qkv_rope_cache(w.qkv, st->cosT, st->sinT, w.q, kc, vc, st->S + step, B, 1, Hq, Hkv, D, st->Tmax, st->Tnew,
-                                   step, s));
+            TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
+                                       st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
                                 st->Tmax, st->nsplit, scale, s));
             TRY(o3v_gemv_bf16(w.att, lw.o_w, nullptr, st->x, st->x, B, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));

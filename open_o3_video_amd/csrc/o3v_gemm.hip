@@ -18,6 +18,7 @@
 #define EPI_RESIDUAL 1
 #define EPI_GELU 2
 #define EPI_SWIGLU 3
+#define EPI_QKVROPE 4  // decode only: bias, M-RoPE, write q / append k,v to the cache (TF:557-599, :652-664)
 
 namespace {
 
@@ -170,11 +171,18 @@ __device__ __forceinline__ void fma8(const u32x4& w, const u32x4& x, float& acc)
     }
 }
 
+struct RopeArgs {  // EPI_QKVROPE destinations (one token per row m, cache slot `slot`, table row m*cs_stride+cs_off)
+    const bf16_t *cosT, *sinT;
+    bf16_t *qout, *kc, *vc;
+    int slot, Hq, Hkv, D, Tmax, cs_stride, cs_off;
+};
+
 template <int M, int R, int KS, int EPI, bool NORM>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
-                                                        float eps, int N, int K, int ldx, int ldw, int ldo, int ldr) {
+                                                        float eps, int N, int K, int ldx, int ldw, int ldo, int ldr,
+                                                        RopeArgs ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M*K bf16] [KS>1: 4*R*M f32]
     constexpr int RG = 4 / KS;                                   // row groups per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,6 +242,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             rows[2 * r] = g;
             rows[2 * r + 1] = g + 16;
         }
+    } else if (EPI == EPI_QKVROPE) {
+        // a wave owns the rotary pair (j, j + D/2) of one head, so the rotation needs no second wave
+        const int half = ra.D >> 1;
+        rows[0] = (grp / half) * ra.D + (grp % half);
+        rows[R - 1] = rows[0] + half;
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) rows[r] = grp * R + r;
@@ -307,6 +320,31 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             }
     }
     if (lane != 0) return;
+    if (EPI == EPI_QKVROPE) {
+        if (rows[0] >= N) return;
+        const int half = ra.D >> 1, head = rows[0] / ra.D, j = rows[0] % ra.D;
+        const float b0 = bias ? bf2f(bias[rows[0]]) : 0.f, b1 = bias ? bf2f(bias[rows[R - 1]]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float v0 = rbf(acc[0][m] + b0), v1 = rbf(acc[R - 1][m] + b1);
+            if (head >= ra.Hq + ra.Hkv) {  // v: no rotation
+                bf16_t* dst = ra.vc + (((size_t)m * ra.Hkv + (head - ra.Hq - ra.Hkv)) * ra.Tmax + ra.slot) * ra.D;
+                dst[j] = f2bf(v0);
+                dst[j + half] = f2bf(v1);
+                continue;
+            }
+            const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + j;
+            const float c = bf2f(ra.cosT[cs]), sn = bf2f(ra.sinT[cs]);
+            // TF:598-599 in bf16: bf16(bf16(x*cos) + bf16(rotate_half(x)*sin))
+            const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
+            const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
+            bf16_t* dst = head < ra.Hq ? ra.qout + ((size_t)m * ra.Hq + head) * ra.D
+                                       : ra.kc + (((size_t)m * ra.Hkv + (head - ra.Hq)) * ra.Tmax + ra.slot) * ra.D;
+            dst[j] = f2bf(o0);
+            dst[j + half] = f2bf(o1);
+        }
+        return;
+    }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
@@ -343,20 +381,25 @@ struct GemvArgs {
     float eps;
     int N, K, ldx, ldw, ldo, ldr, epi;
     hipStream_t s;
+    RopeArgs ra;
 };
 
 template <int M, int R, int KS, bool NORM>
 int launch_gemv(const GemvArgs& a) {
-    const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : R;
-    const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
+    const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : (a.epi == EPI_QKVROPE ? 1 : R);
+    const int outs = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 2 : a.N;
     const int per_block = per_wave * (4 / KS);
     dim3 grid((outs + per_block - 1) / per_block), block(256);
     const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)4 * R * M * 4 + (NORM ? 4 * M * 4 : 0);
     if (shmem > 160 * 1024) return O3V_ERR_SHAPE;
 #define O3V_GV(E)                                                                                                         \
     O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,  \
-                a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr)
+                a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra)
     switch (a.epi) {
+        case EPI_QKVROPE:
+            if (R != 2 || !NORM) return O3V_ERR_ARG;
+            if constexpr (R == 2 && NORM) O3V_GV(EPI_QKVROPE);
+            break;
         case EPI_NONE: O3V_GV(EPI_NONE); break;
         case EPI_RESIDUAL: O3V_GV(EPI_RESIDUAL); break;
         case EPI_GELU: O3V_GV(EPI_GELU); break;
@@ -372,6 +415,7 @@ int launch_gemv_m(const GemvArgs& a) {
     // Decomposition: enough waves to keep >= 32 KiB of weight loads in flight per CU, whole 512-k steps per wave.
     const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
     const int steps = (a.K / 8 + 63) / 64;
+    if (a.epi == EPI_QKVROPE) return launch_gemv<M, 2, 2, NORM>(a);
     if (a.epi == EPI_SWIGLU) {
         if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM>(a);  // 2 (gate,up) pairs per wave
         return launch_gemv<M, 2, 1, NORM>(a);
@@ -411,14 +455,14 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
 
 static int gemv_dispatch(const void* X, const void* W, const void* bias, const void* res, void* out, const void* norm_w,
                          float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
-                         hipStream_t stream) {
-    if (!X || !W || !out || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
+                         hipStream_t stream, const RopeArgs* ra = nullptr) {
+    if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 8) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
     GemvArgs a{(const bf16_t*)X, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w,
-               (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream};
+               (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream, ra ? *ra : RopeArgs{}};
     int rc;
 #define O3V_M(MM) rc = norm_w ? launch_gemv_m<MM, true>(a) : launch_gemv_m<MM, false>(a)
     switch (M) {
@@ -448,4 +492,19 @@ extern "C" int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, 
                                   int epilogue, hipStream_t stream) {
     if (!norm_w) return O3V_ERR_ARG;
     return gemv_dispatch(X, W, bias, res, out, norm_w, eps, M, N, K, ldx, ldw, ldo, ldr, epilogue, stream);
+}
+
+// Decode q/k/v projection with everything around it fused: RMSNorm prologue, bias, M-RoPE, q written to qout[M,Hq,D],
+// k and v appended to the cache at `slot` (TF:733-736 norm, :636-664 projection + rope + cache update).
+extern "C" int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* bias, int M,
+                                      int K, int ldx, const void* cosT, const void* sinT, void* qout, void* kcache,
+                                      void* vcache, int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off,
+                                      hipStream_t stream) {
+    if (!norm_w || !cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 ||
+        (D & 1))
+        return O3V_ERR_ARG;
+    RopeArgs ra{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache,
+                slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
+    return gemv_dispatch(X, W, bias, nullptr, nullptr, norm_w, eps, M, (Hq + 2 * Hkv) * D, K, ldx, K, 0, 0, EPI_QKVROPE, stream,
+                         &ra);
 }

@@ -263,7 +263,7 @@ class O3VEngine:
         k_lo = torch.from_numpy(pad_rep.astype(np.int32)).to(self.dev)
         rid = torch.tensor(list(row_ids) if row_ids is not None else list(range(B)), dtype=torch.int32, device=self.dev)
         n_rep_total = B * tc.num_attention_heads
-        nsplit = max(1, min(64, (Tmax + 63) // 64, max(1, 1024 // max(1, B * tc.num_key_value_heads))))
+        nsplit = max(1, min(64, (Tmax + 127) // 128, max(1, 2048 // max(1, B * tc.num_key_value_heads))))
         part_o = torch.empty(n_rep_total * nsplit * tc.head_dim, dtype=torch.float32, device=self.dev)
         part_ml = torch.empty(n_rep_total * nsplit * 2, dtype=torch.float32, device=self.dev)
         scratch = torch.empty((B, V if do_sample else 256), dtype=torch.float32, device=self.dev)

@@ -155,6 +155,40 @@ def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
     close_bf16(out, ref, ulps=1, atol=1e-3, frac=0.9995)
 
 
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(1, 28, 4, 128, 3584), (3, 7, 1, 128, 896), (8, 4, 2, 32, 128)])
+def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
+    """Fully fused decode q/k/v projection == rmsnorm -> gemv(+bias) -> qkv_rope_cache (bit-identical outputs)."""
+    import ctypes as C
+    from open_o3_video_amd import ops, _lib
+    g = torch.Generator().manual_seed(M + Hq)
+    N, Tmax, Tnew, step, slot = (Hq + 2 * Hkv) * D, 40, 6, 4, 33
+    x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    ang = torch.rand(M, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # unfused chain
+    qkv = torch.empty(M, N, dtype=BF, device=dev)
+    _lib.call("o3v_gemv_norm_bf16", P(x), P(nw), 1e-6, P(w), P(bias), None, P(qkv), M, N, K, K, K, N, 0, ops.EPI_NONE, st)
+    q1 = torch.zeros(M, Hq, D, dtype=BF, device=dev)
+    k1 = torch.zeros(M, Hkv, Tmax, D, dtype=BF, device=dev)
+    v1 = torch.zeros_like(k1)
+    _lib.call("o3v_qkv_rope_cache", P(qkv), P(cos), P(sin), P(q1), P(k1), P(v1), slot, M, 1, Hq, Hkv, D, Tmax, Tnew, step, st)
+    # fused
+    q2, k2, v2 = torch.zeros_like(q1), torch.zeros_like(k1), torch.zeros_like(v1)
+    _lib.call("o3v_gemv_norm_qkv_rope", P(x), P(nw), 1e-6, P(w), P(bias), M, K, K, P(cos), P(sin), P(q2), P(k2), P(v2), slot,
+              Hq, Hkv, D, Tmax, Tnew, step, st)
+    # the fused kernel splits K over 2 waves, the unfused gemv may not: allow 1 bf16 ulp on the projection
+    close_bf16(q2, q1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(k2, k1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(v2, v1.float(), ulps=1, atol=2e-3, frac=0.999)
+    assert (k2[:, :, :slot] == 0).all() and (k2[:, :, slot + 1:] == 0).all()
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from open_o3_video_amd import ops, _lib
     a = torch.zeros(4, 100, dtype=BF, device=dev)
