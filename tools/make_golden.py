@@ -322,3 +322,142 @@ if __name__ == "__main__":
         g6_g7()
     if "g8" in which:
         g8_logits_processors()
+
+
+# ------------------------------------------------------------------------------------------------ G9 rewards / spans
+def _import_with_stubs(name, path, stubs):
+    import importlib.util
+    import importlib.machinery
+    for s in stubs:
+        if s not in sys.modules:
+            m = types.ModuleType(s)
+            m.__spec__ = importlib.machinery.ModuleSpec(s, None)
+            if s == "rouge_score":
+                m.rouge_scorer = types.SimpleNamespace(RougeScorer=None)  # free-form ROUGE branch is never exercised
+            sys.modules[s] = m
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _functions_from_source(path, names):
+    """Compile selected top-level functions of a reference script whose module-level imports are unavailable."""
+    import ast
+    import json as _json
+    import re as _re
+    tree = ast.parse(open(path).read())
+    ns = {"re": _re, "json": _json, "print": lambda *a, **k: None}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+            exec(code, ns)
+    return ns
+
+
+COMPLETIONS = [
+    "<think>The man <obj>man</obj><box>[10, 20, 110, 220]</box>at<t>3.5</t>s picks the ball.</think><answer>A red ball</answer>",
+    "<think><obj>dog</obj><box>[0.1, 0.2, 0.5, 0.9]</box>at<t>1.0</t>s then <obj>cat</obj><box>[5,5,50,60]</box><box>[7,7,40,40]</box>at<t>12</t>s</think><answer>the dog runs</answer>",
+    "<think>no tags here</think><answer>B</answer>",
+    "<think>From <t>2.0</t>s the car moves until <t>7.5</t>s</think><answer>From <t>2.0</t>s to <t>7.5</t>s</answer>",
+    "<think>at <t>4</t>s and <t>30.25</t>s</think><answer>From <t>9</t>s to <t>3</t>s</answer>",
+    "<think>reasoning</think><answer>Correct Option: C\n[3.0, 9.0]</answer>",
+    "<think>see <t>5.0</t>s <t>6.0</t>s</think><answer>Correct Option: (B)</answer>",
+    "<answer>only answer</answer>",
+    "<think>unclosed think<answer>x</answer>",
+    "<think>a</think><think>b</think><answer>x</answer>",
+    "<think><obj>cup</obj><box>[12, 30, 200, 180]</box></think><answer><box>[15, 28, 190, 185]</box></answer>",
+    "<think><obj>cup</obj><box>[12, 30, 200]</box><box>[1,2,3,4]</box></think><answer><box>[15, 28, 190, 185]</box></answer>",
+    "<think><obj>cup</obj><box>not json</box></think><answer><box>[bad]</box></answer>",
+    "<think><obj>a</obj><box>[1,2,3,4]</box>at<t>x</t>s <obj>b</obj><box>[100, 50, 300, 250]</box>at<t>8.2</t>s</think><answer>ok</answer>",
+    "<think><obj>person</obj><box>[320, 100, 420, 300]</box>at<t>2.2</t>s. <obj>person</obj><box>[30, 10, 90, 80]</box>at<t>15.0</t>s</think>\n<answer>He walks away</answer>",
+    "<think><obj>x</obj><t>1</t>s<box>[1,2,3,4]</box></think><answer> spaced answer </answer>",
+    "plain text without any tag",
+    "<think><obj>unbalanced<box>[1,2,3,4]</box>at<t>1</t>s</think><answer>y</answer>",
+    "<think><t>1.5</t>s <t>2.5.5</t>s</think><answer>From <t>1</t>s to <t>2</t>s</answer>",
+    "<think><obj>ball</obj><box>[0, 0, 640, 360]</box>at<t>0.0</t>s</think><answer>From <t>0.5</t>s to <t>10</t>s</answer>",
+    "<think>t</think><answer>(A)</answer>",
+    "<think>t</think><answer>A.</answer>",
+    "<think>t</think><answer>[A]</answer>",
+    "<think>t</think><answer>AB</answer>",
+    "<think><obj>kid</obj><box>[[10, 10, 60, 90], [200, 40, 260, 120]]</box>at<t>4.9</t>s</think><answer>two kids</answer>",
+    "<think><obj>sign</obj><box>[50, 60, 40, 30]</box>at<t>3</t>s</think><answer>reversed box</answer>",
+    "<think>The <obj>bowling ball</obj><box>[301, 212, 345, 260]</box>at<t>00:07</t>s</think><answer>blue</answer>",
+    "<think>x</think><answer>```json\n{\"3\": [10, 20, 30, 40], \"4\": [11, 21, 31, 41]}\n```</answer>",
+    "<think>x</think><answer>{'5': [1, 2, 3, 4], '6': [2, 3, 4, 5]}</answer>",
+    "<think>x</think><answer>[{\"1\": [1,2,3,4]}, {\"2\": [5,6,7,8]}]</answer>",
+    "<think>x</think><answer>[[1, [1,2,3,4]], [2, [5,6,7,8]]]</answer>",
+    "<think>x</think><answer>{\"7\": [1, 2, 3, 4], \"8\": [5, 6, 7</answer>",
+    "<think>x</think><answer>The event is from 1:05 to 2:10.</answer>",
+    "<think>x</think><answer>From 3.5 to 12 seconds</answer>",
+    "<think>x</think><answer>between 4 and 9 and 11</answer>",
+    "From <t>6</t>s to <t>14.5</t>s",
+    "<think><obj>man</obj><box>[10, 20, 110, 220]</box>at<t>3.5</t>s</think><answer>From <t>3</t>s to <t>4</t>s</answer><answer>dup</answer>",
+    "<think><obj>w</obj><box>[0.05, 0.1, 0.3, 0.6]</box>at<t>2.95</t>s <obj>w2</obj><box>[0.5, 0.5, 0.9, 0.95]</box>at<t>6.1</t>s</think><answer>normalised boxes</answer>",
+]
+
+
+def g9_rewards_spans():
+    rf = _import_with_stubs("ref_reward_func", "/root/reference/src/r1-v/src/open_r1/reward_func.py", ["rouge_score"])
+    tts = _import_with_stubs("ref_tts", "/root/reference/eval/tts.py", ["cv2"])
+    vs = _functions_from_source("/root/reference/eval/test/test_vstar_multi_images.py",
+                                {"extract_timestamps", "fix_incomplete_json", "extract_bounding_boxes"})
+    out = {"completions": COMPLETIONS, "cases": [], "claims": [], "tts": [], "vstar_ts": [], "vstar_bb": [], "iou": []}
+    comps = [[{"role": "assistant", "content": c}] for c in COMPLETIONS]
+    n = len(COMPLETIONS)
+    key_frames = [{"idx": 3, "time": 3.0}, {"idx": 8, "time": 8.0}, {"idx": 15, "time": 15.5}]
+    key_items = {"3": {"man": [[0.0, 0.05, 0.2, 0.6]], "ball": [[0.45, 0.55, 0.55, 0.75]]},
+                 "8": {"b": [[0.15, 0.14, 0.47, 0.7]]},
+                 "15": {"person": [[0.04, 0.02, 0.15, 0.23], [0.5, 0.3, 0.66, 0.84]]}}
+    base = {"key_frames": [key_frames] * n, "key_items": [key_items] * n, "image_size": [(640, 360)] * n,
+            "image_size_refine": [(420, 224)] * n}
+    task_answers = {
+        "temporal-spatial free-form QA": "A red ball",
+        "General video QA Free-form": "the dog runs fast",
+        "General video QA MCQ": "B",
+        "temporal QA": "[2.0, 8.0]",
+        "temporal QA (MCQ)": "C\n[3.0, 9.0]",
+        "visual QA": "The cup is <box>[20, 50, 300, 290]</box>",
+    }
+    funcs = ["ans_tiou_reward", "ans_viou_reward", "format_reward", "thk_temporal_segment_reward",
+             "thk_temporal_point_reward", "thk_spatial_reward", "ans_acc_reward"]
+    for task, ans in task_answers.items():
+        for sp in (0.0, 0.5, 0.9):
+            kw = dict(base, task=[task] * n, answer=[ans] * n, step_percent=[sp] * n)
+            rec = {"task": task, "answer": ans, "step_percent": sp, "rewards": {}}
+            for fn in funcs:
+                if fn == "ans_acc_reward" and "MCQ" not in task and task not in ("visual QA", "temporal QA"):
+                    continue  # free-form branch needs the real rouge_score package (absent): unpinned
+                if sp != 0.0 and fn != "thk_temporal_point_reward":
+                    continue
+                f = getattr(rf, fn)
+                import copy
+                k2 = copy.deepcopy(kw)
+                if fn in ("ans_acc_reward", "ans_tiou_reward", "ans_viou_reward"):
+                    a = k2.pop("answer")
+                    r = f(copy.deepcopy(comps), a, **k2)
+                else:
+                    r = f(copy.deepcopy(comps), **k2)
+                rec["rewards"][fn] = [float(x) for x in r]
+            out["cases"].append(rec)
+    for c in COMPLETIONS:
+        import re as _re
+        m = _re.search(r"<think>(.*?)</think>", c, _re.DOTALL)
+        out["claims"].append(rf.parse_temporal_spatial_reasoning_process(m.group(1)) if m else None)
+        out["tts"].append(tts.parse_patterns(c))
+        out["vstar_ts"].append(vs["extract_timestamps"](c))
+        out["vstar_bb"].append(vs["extract_bounding_boxes"](c, {"width": 1280, "height": 720}, 644, 364))
+    boxes = [[0, 0, 10, 10], [5, 5, 15, 15], [20, 20, 30, 30], [0, 0, 0, 0], [1.5, 2.5, 8.25, 9.75], "bad", [1, 2, 3]]
+    for a in boxes[:5]:
+        for b in boxes:
+            out["iou"].append([a, b, float(rf.calculate_iou(a, b))])
+    out["tts_frame_idx"] = [[t, fps, n_, (round(t * fps) if round(t * fps) < n_ else None)] for t, fps, n_ in
+                            [(0.5, 1.0, 16), (2.5, 1.0, 16), (3.5, 2.0, 8), (7.26, 1.4527, 32), (100, 1.0, 16)]]
+    out["relevance"] = [[s, tts.relevance_mapping(s)] for s in (0, 1, 2, -1, 5)]
+    with open(os.path.join(GOLD, "g9_spans_rewards.json"), "w") as f:
+        json.dump(out, f)
+    print("G9 written:", len(out["cases"]), "task cases x", n, "completions")
+
+
+if __name__ == "__main__" and "g9" in sys.argv[1:]:
+    g9_rewards_spans()
