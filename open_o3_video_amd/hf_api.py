@@ -1,0 +1,195 @@
+"""HF-style facade (facade 1): an object the Open-o3-Video GRPO trainer can use as `model`.
+
+    model = Qwen2_5_VLForConditionalGeneration.from_pretrained(local_dir, torch_dtype=torch.bfloat16, ...)
+    ids   = model.generate(**prompt_inputs, generation_config=GenerationConfig(...))     # R:grpo_trainer.py:581-582
+    logit = model(input_ids, attention_mask=..., pixel_values=..., image_grid_thw=...).logits   # R:grpo_trainer.py:375
+
+Same argument names and output conventions as transformers' Qwen2_5_VLForConditionalGeneration.generate:
+returns i64 [B*G, S+T], prompt columns preserved, rows padded with pad_token_id after EOS, row b*G+g is completion g
+of prompt b (TF:modeling_qwen2_5_vl.py:1493-1579).  Unlike the reference it runs the ViT and the prefill once per
+prompt and fans the KV cache out to the G completions.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import O3VConfig
+from .engine import O3VEngine
+from .weights import DeviceWeights, getter_from_dict, getter_from_safetensors_dir
+
+MAX_ROWS = 8  # sequences per engine call (decode GEMV batch)
+
+
+class GenerationConfigLike(SimpleNamespace):
+    """Duck-typed subset of transformers.GenerationConfig (max_new_tokens, do_sample, temperature, top_p,
+    repetition_penalty, num_return_sequences, pad_token_id, eos_token_id)."""
+
+
+def _get(gc, name, default):
+    v = getattr(gc, name, None) if gc is not None else None
+    return default if v is None else v
+
+
+class Qwen2_5_VLForConditionalGeneration:
+    def __init__(self, cfg: O3VConfig, engine: O3VEngine):
+        self.engine = engine
+        self.o3v_config = cfg
+        self.config = SimpleNamespace(_name_or_path=cfg.name_or_path, image_token_id=cfg.image_token_id,
+                                      video_token_id=cfg.video_token_id, eos_token_id=cfg.eos_token_id,
+                                      pad_token_id=cfg.pad_token_id, vocab_size=cfg.text.vocab_size)
+        self.warnings_issued = {}          # R:grpo_trainer.py:330 touches it
+        self.generation_config = GenerationConfigLike(max_new_tokens=20, do_sample=False, temperature=1.0, top_p=1.0,
+                                                      repetition_penalty=1.0, num_return_sequences=1,
+                                                      pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id)
+        self.training = False
+        self._seed = 0
+
+    # ---- construction
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=None, attn_implementation=None, use_cache=True, device="cuda", **_):
+        """Local checkpoint directory only (config.json + *.safetensors).  `attn_implementation` is accepted and
+        ignored: attention always runs in the hand-written HIP kernels."""
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local checkpoint directory (this build never downloads)")
+        if torch_dtype not in (None, torch.bfloat16, "bfloat16", "auto"):
+            raise ValueError("the MI355X path computes in bf16 (torch_dtype=torch.bfloat16)")
+        cfg = O3VConfig.from_pretrained(path)
+        w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device)
+        return cls(cfg, O3VEngine(cfg, w))
+
+    @classmethod
+    def from_state_dict(cls, cfg_dict: dict, state_dict, device="cuda"):
+        cfg = O3VConfig.from_dict(cfg_dict)
+        return cls(cfg, O3VEngine(cfg, DeviceWeights(cfg, getter_from_dict(state_dict), device)))
+
+    # ---- nn.Module-ish surface the trainer touches
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training (backward / optimizer) is out of scope of the generate path")
+        return self
+
+    def to(self, *_, **__):
+        return self
+
+    @property
+    def device(self):
+        return self.engine.dev
+
+    def manual_seed(self, seed: int):
+        self._seed = int(seed)
+
+    # ---- generate
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
+                 pixel_values_videos=None, video_grid_thw=None, generation_config=None, **kw):
+        if pixel_values_videos is not None:
+            raise NotImplementedError("native video inputs (pixel_values_videos): the reference feeds frames as images "
+                                      "(R:grpo_trainer.py:540-548); pass pixel_values / image_grid_thw")
+        gc = generation_config or self.generation_config
+        G = int(kw.get("num_return_sequences", _get(gc, "num_return_sequences", 1)))
+        T = int(kw.get("max_new_tokens", _get(gc, "max_new_tokens", 20)))
+        do_sample = bool(kw.get("do_sample", _get(gc, "do_sample", False)))
+        eos = kw.get("eos_token_id", _get(gc, "eos_token_id", self.o3v_config.eos_token_id))
+        eos = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])
+        pad = int(kw.get("pad_token_id", _get(gc, "pad_token_id", self.o3v_config.pad_token_id)))
+        common = dict(max_new_tokens=T, eos_token_ids=eos, pad_token_id=pad,
+                      repetition_penalty=float(kw.get("repetition_penalty", _get(gc, "repetition_penalty", 1.0))),
+                      do_sample=do_sample, temperature=float(kw.get("temperature", _get(gc, "temperature", 1.0)) or 1.0),
+                      top_p=float(kw.get("top_p", _get(gc, "top_p", 1.0)) or 1.0), seed=self._seed)
+        self._seed += 1
+        ids = torch.as_tensor(input_ids).cpu().numpy()
+        B = ids.shape[0]
+        mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
+        grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()
+        per_prompt_pixels = self._split_pixels(ids, pixel_values, grid)
+        rows = []
+        if G > MAX_ROWS:
+            raise ValueError(f"num_return_sequences={G} > {MAX_ROWS}")
+        step = max(1, MAX_ROWS // G)
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            pv, gr = self._cat_pixels(per_prompt_pixels[b0:b1])
+            out = self.engine.generate(ids[b0:b1], None if mask is None else mask[b0:b1], pixel_values=pv, image_grid_thw=gr,
+                                       num_return_sequences=G, row_ids=list(range(b0 * G, b1 * G)), return_margins=False,
+                                       **common)
+            rows.append(out.sequences)
+        L = max(r.shape[1] for r in rows)
+        rows = [torch.nn.functional.pad(r, (0, L - r.shape[1]), value=pad) for r in rows]
+        return torch.cat(rows, dim=0)
+
+    def _split_pixels(self, ids, pixel_values, grid):
+        """Pixel rows / grid rows belonging to each prompt (placeholders are consumed in order)."""
+        B = ids.shape[0]
+        if pixel_values is None or grid is None:
+            return [(None, None)] * B
+        unit = self.o3v_config.vision.merge_unit
+        tok_per_img = (grid[:, 0] * grid[:, 1] * grid[:, 2]) // unit
+        n_tok = (ids == self.o3v_config.image_token_id).sum(axis=1)
+        out, gi, prow = [], 0, 0
+        pv = torch.as_tensor(pixel_values)
+        for b in range(B):
+            need, g0 = int(n_tok[b]), gi
+            got = 0
+            while got < need:
+                if gi >= len(grid):
+                    raise ValueError("Image features and image tokens do not match")
+                got += int(tok_per_img[gi])
+                gi += 1
+            if got != need:
+                raise ValueError("Image features and image tokens do not match")
+            rows_n = int((grid[g0:gi, 0] * grid[g0:gi, 1] * grid[g0:gi, 2]).sum())
+            out.append((pv[prow:prow + rows_n], grid[g0:gi]))
+            prow += rows_n
+        return out
+
+    @staticmethod
+    def _cat_pixels(parts):
+        pvs = [p for p, _ in parts if p is not None and len(p)]
+        if not pvs:
+            return None, None
+        return torch.cat(pvs, dim=0), np.concatenate([g for p, g in parts if p is not None and len(p)], axis=0)
+
+    # ---- forward (logits), as _get_per_token_logps calls it
+    @torch.no_grad()
+    def __call__(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, **kw):
+        ids = torch.as_tensor(input_ids).cpu().numpy()
+        B = ids.shape[0]
+        mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
+        grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()
+        parts = self._split_pixels(ids, pixel_values, grid)
+        outs = []
+        for b in range(B):  # one prompt at a time keeps the [L, V] logits slab bounded (7B: 1.4 GB per 4.6k tokens)
+            pv, gr = parts[b]
+            outs.append(self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], pixel_values=pv,
+                                                   image_grid_thw=gr))
+        return SimpleNamespace(logits=torch.cat(outs, dim=0))
+
+    forward = __call__
+
+    @torch.no_grad()
+    def per_token_logps(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None):
+        """Fast path for R:grpo_trainer.py:371-384: never keeps more than one row of logits alive."""
+        ids = torch.as_tensor(input_ids)
+        out = []
+        mask = None if attention_mask is None else torch.as_tensor(attention_mask)
+        parts = self._split_pixels(ids.cpu().numpy(), pixel_values,
+                                   None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy())
+        for b in range(ids.shape[0]):
+            pv, gr = parts[b]
+            lg = self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], pixel_values=pv,
+                                            image_grid_thw=gr)
+            out.append(self.engine.per_token_logps(lg, ids[b:b + 1]))
+        return torch.cat(out, dim=0)
+
+
+# the north-star text names the Qwen2-VL class; both resolve to the same engine
+Qwen2VLForConditionalGeneration = Qwen2_5_VLForConditionalGeneration

@@ -1,0 +1,148 @@
+"""GSPO group rollout around the generate path (forward side of Qwen2VLGRPOTrainer.compute_loss,
+R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:402-742): G sampled completions per prompt, EOS masks, per-token
+log-probs of policy and reference, KL, the seven rewards, group advantages, the sequence-level clipped GSPO
+objective value, and the logging record gathered across ranks.  Backward / optimizer are out of scope.
+
+Differences from the reference that do not change results: the ViT and the prompt prefill run once per prompt and are
+shared by the G completions (the reference recomputes them G times in generate and 2G times for the log-probs,
+R:…:601-606), logits are never materialised for the whole batch, and the six metric gathers are one all_gather.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import dist as o3v_dist
+
+
+# ------------------------------------------------------------------------------------------------ pure math
+def completion_mask(completion_ids: torch.Tensor, eos_token_id: int) -> torch.Tensor:
+    """1 up to and including the first EOS, 0 after (R:…:590-596)."""
+    is_eos = completion_ids == eos_token_id
+    T = completion_ids.shape[1]
+    eos_idx = torch.full((completion_ids.shape[0],), T, dtype=torch.long, device=completion_ids.device)
+    any_eos = is_eos.any(dim=1)
+    eos_idx[any_eos] = is_eos.int().argmax(dim=1)[any_eos]
+    seq = torch.arange(T, device=completion_ids.device).expand(completion_ids.shape[0], -1)
+    return (seq <= eos_idx.unsqueeze(1)).int()
+
+
+def per_token_kl(ref_logps: torch.Tensor, logps: torch.Tensor) -> torch.Tensor:
+    """k3 estimator with the log-ratio clamped to [-10, 10] (R:…:635-636)."""
+    x = torch.clamp(ref_logps - logps, min=-10, max=10)
+    return torch.exp(x) - x - 1
+
+
+def group_advantages(rewards: torch.Tensor, G: int):
+    """(r - mean_group) / (std_group + 1e-4), unbiased std (R:…:675-681).  Returns (advantages, std per row)."""
+    grouped = rewards.view(-1, G)
+    mean = grouped.mean(dim=1).repeat_interleave(G, dim=0)
+    std = grouped.std(dim=1).repeat_interleave(G, dim=0)
+    return (rewards - mean) / (std + 1e-4), std
+
+
+def gspo_loss(logps, old_logps, ref_logps, advantages, mask, beta=0.04, eps_low=0.2, eps_high=0.2, gspo=True):
+    """Sequence-level importance ratio, clipped surrogate, + beta*KL, masked mean per sequence (R:…:691-706)."""
+    log_ratio = logps - old_logps
+    m = mask.to(logps.dtype)
+    denom = m.sum(-1).clamp(min=1.0)
+    if gspo:
+        liw = ((log_ratio * m).sum(-1) / denom).unsqueeze(-1)
+    else:
+        liw = log_ratio
+    c1 = torch.exp(liw)
+    c2 = torch.clamp(c1, 1 - eps_low, 1 + eps_high)
+    a = advantages.unsqueeze(1)
+    ptl = -torch.min(c1 * a, c2 * a) + beta * per_token_kl(ref_logps, logps)
+    return ((ptl * m).sum(-1) / denom).mean()
+
+
+# ------------------------------------------------------------------------------------------------ rollout
+@dataclass
+class RolloutResult:
+    prompt_completion_ids: torch.Tensor
+    completion_ids: torch.Tensor
+    completion_mask: torch.Tensor
+    per_token_logps: torch.Tensor
+    ref_per_token_logps: torch.Tensor
+    per_token_kl: torch.Tensor
+    rewards_per_func: torch.Tensor
+    rewards: torch.Tensor
+    advantages: torch.Tensor
+    loss: torch.Tensor
+    completions: List[str]
+    metrics: Dict[str, float] = field(default_factory=dict)
+
+
+class GroupRollout:
+    """model / ref_model: open_o3_video_amd.hf_api.Qwen2_5_VLForConditionalGeneration (ref_model None -> the policy
+    itself, as the reference's PEFT branch does).  decode: ids -> text (tokenizer.batch_decode)."""
+
+    def __init__(self, model, reward_funcs: Sequence[Callable], decode: Callable[[torch.Tensor], List[str]],
+                 eos_token_id: int, pad_token_id: int, ref_model=None, num_generations: int = 4,
+                 max_completion_length: int = 768, max_prompt_length: Optional[int] = 16384, beta: float = 0.04,
+                 epsilon_low: float = 0.2, epsilon_high: float = 0.2, temperature: float = 1.0, top_p: float = 0.95,
+                 gspo: bool = True):
+        self.model, self.ref_model = model, ref_model
+        self.reward_funcs = list(reward_funcs)
+        self.decode = decode
+        self.eos, self.pad = eos_token_id, pad_token_id
+        self.G, self.T = num_generations, max_completion_length
+        self.max_prompt_length = max_prompt_length
+        self.beta, self.el, self.eh = beta, epsilon_low, epsilon_high
+        self.temperature, self.top_p, self.gspo = temperature, top_p, gspo
+
+    @torch.no_grad()
+    def step(self, prompt_inputs: dict, example: dict) -> RolloutResult:
+        """prompt_inputs: processor output (input_ids, attention_mask, pixel_values, image_grid_thw) of ONE prompt
+        (the reference hard-wires batch 1, R:…:410-470).  example: the dataset row; every column except
+        prompt/completion is repeated G times and handed to the reward functions (R:…:648-656)."""
+        ids, mask = prompt_inputs["input_ids"], prompt_inputs["attention_mask"]
+        if self.max_prompt_length is not None:          # left truncation of ids only, as the reference (R:…:569-578)
+            ids, mask = ids[:, -self.max_prompt_length:], mask[:, -self.max_prompt_length:]
+        pv, grid = prompt_inputs.get("pixel_values"), prompt_inputs.get("image_grid_thw")
+        from .hf_api import GenerationConfigLike
+        gc = GenerationConfigLike(max_new_tokens=self.T, do_sample=True, top_p=self.top_p, temperature=self.temperature,
+                                  num_return_sequences=self.G, pad_token_id=self.pad, eos_token_id=self.eos,
+                                  repetition_penalty=1.0)
+        pc = self.model.generate(input_ids=ids, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
+                                 generation_config=gc)
+        S = ids.shape[1]
+        comp = pc[:, S:]
+        cmask = completion_mask(comp, self.eos)
+        full_mask = torch.cat([mask.to(pc.device).repeat_interleave(self.G, dim=0), torch.ones_like(comp)], dim=1)
+        rep = lambda t: None if t is None else torch.as_tensor(t).repeat(pc.shape[0], *([1] * (torch.as_tensor(t).dim() - 1)))
+        lp = self.model.per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
+        ref = (self.ref_model or self.model).per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
+        kl = per_token_kl(ref, lp)
+        texts = self.decode(comp)
+        completions = [[{"role": "assistant", "content": t}] for t in texts]
+        cols = {k: [v] * self.G for k, v in example.items() if k not in ("prompt", "completion")}
+        rpf = torch.zeros(len(texts), len(self.reward_funcs), device=pc.device)
+        for i, fn in enumerate(self.reward_funcs):
+            rpf[:, i] = torch.tensor(fn(prompts=[example.get("prompt")] * self.G, completions=completions, **cols),
+                                     dtype=torch.float32, device=pc.device)
+        rewards = rpf.sum(dim=1)
+        adv, std = group_advantages(rewards, self.G)
+        loss = gspo_loss(lp, lp, ref, adv, cmask, self.beta, self.el, self.eh, self.gspo)
+        res = RolloutResult(pc, comp, cmask, lp, ref, kl, rpf, rewards, adv, loss, texts)
+        res.metrics = self.gather_metrics(res, std)
+        return res
+
+    def gather_metrics(self, res: RolloutResult, std: torch.Tensor) -> Dict[str, float]:
+        """One all_gather of [G, n_funcs+4] replaces six gather_for_metrics (R:…:711-738)."""
+        m = res.completion_mask.to(torch.float32)
+        mean_kl = ((res.per_token_kl * m).sum(1) / m.sum(1).clamp(min=1.0))
+        rec = torch.cat([res.rewards_per_func, res.rewards[:, None], m.sum(1, keepdim=True), std[:, None], mean_kl[:, None]], dim=1)
+        allr = o3v_dist.all_gather_records(rec.contiguous())
+        nf = res.rewards_per_func.shape[1]
+        per_dev = allr[:, nf].view(-1, self.G)
+        out = {"completion_length": allr[:, nf + 1].mean().item(), "reward": allr[:, nf].mean().item(),
+               "reward_std": allr[:, nf + 2].mean().item(), "kl": allr[:, nf + 3].mean().item(),
+               "all_wrong": (per_dev <= 1).all(dim=1).float().mean().item(),
+               "all_correct": (per_dev >= 2).all(dim=1).float().mean().item()}
+        for i, fn in enumerate(self.reward_funcs):
+            out[f"rewards/{getattr(fn, '__name__', str(i))}"] = allr[:, i].mean().item()
+        return out

@@ -1,0 +1,172 @@
+"""vLLM-style facade (facade 2): `LLM(...).generate(inputs, sampling_params)` as
+R:eval/inference_example.py:15-29,75-82 and R:eval/models/model_vllm.py:18-33,103,117,125 call it.
+
+    llm = LLM(model=path, tensor_parallel_size=1, max_model_len=81920, gpu_memory_utilization=0.7,
+              limit_mm_per_prompt={"image": 32})
+    out = llm.generate([{"prompt": text, "multi_modal_data": {"image": frames}}], sampling_params=SamplingParams(...))
+    out[0].outputs[0].text
+
+The engine tokenises `prompt` itself, expands each <|image_pad|> to gh*gw/4 placeholders
+(TF:models/qwen2_5_vl/processing_qwen2_5_vl.py:59-62) and runs the fused GPU frame pipeline on the images
+(list of PIL images, a [T,3,H,W] tensor / ndarray as process_vision_info returns it, or a single image).
+temperature == 0 -> greedy; otherwise temperature / top-p sampling with repetition penalty over prompt + output.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import vision_process as vp
+from .config import O3VConfig
+from .engine import O3VEngine
+from .weights import DeviceWeights, getter_from_safetensors_dir
+
+
+@dataclass
+class SamplingParams:
+    temperature: float = 1.0
+    top_p: float = 1.0
+    repetition_penalty: float = 1.0
+    max_tokens: int = 16
+    stop_token_ids: Optional[Sequence[int]] = None
+    n: int = 1
+    seed: Optional[int] = None
+
+
+@dataclass
+class CompletionOutput:
+    index: int
+    text: str
+    token_ids: List[int]
+    finish_reason: str = "length"
+
+
+@dataclass
+class RequestOutput:
+    request_id: str
+    prompt: str
+    prompt_token_ids: List[int]
+    outputs: List[CompletionOutput] = field(default_factory=list)
+
+
+def _load_tokenizer(path):
+    from transformers import AutoTokenizer  # local files only; never downloads
+    return AutoTokenizer.from_pretrained(path, local_files_only=True)
+
+
+class LLM:
+    IMAGE_PAD = "<|image_pad|>"
+
+    def __init__(self, model: str = None, tensor_parallel_size: int = 1, max_model_len: int = 81920,
+                 gpu_memory_utilization: float = 0.9, limit_mm_per_prompt: Optional[dict] = None, dtype: str = "bfloat16",
+                 max_num_seqs: int = 8, engine: Optional[O3VEngine] = None, tokenizer: Any = None,
+                 min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda", **_):
+        if tensor_parallel_size != 1:
+            raise ValueError("the reference runs tensor_parallel_size=1 (R:eval/models/model_vllm.py:21); data parallelism "
+                             "is one engine per GPU (open_o3_video_amd.dist)")
+        if dtype not in ("bfloat16", "auto"):
+            raise ValueError("bf16 only")
+        if engine is None:
+            if model is None or not os.path.isdir(model):
+                raise OSError(f"{model} is not a local checkpoint directory (this build never downloads)")
+            cfg = O3VConfig.from_pretrained(model)
+            engine = O3VEngine(cfg, DeviceWeights(cfg, getter_from_safetensors_dir(model), device))
+            tokenizer = tokenizer or _load_tokenizer(model)
+            pp = os.path.join(model, "preprocessor_config.json")
+            if os.path.exists(pp):
+                import json
+                with open(pp) as f:
+                    pc = json.load(f)
+                min_pixels = pc.get("min_pixels", min_pixels)
+                max_pixels = pc.get("max_pixels", max_pixels)
+        if tokenizer is None:
+            raise ValueError("a tokenizer is required (encode / decode / convert_tokens_to_ids)")
+        self.engine, self.tokenizer = engine, tokenizer
+        self.cfg = engine.cfg
+        self.max_model_len = max_model_len
+        self.limit_mm = dict(limit_mm_per_prompt or {})
+        self.min_pixels, self.max_pixels = min_pixels, max_pixels
+        self._req = 0
+
+    # ---- multimodal input -> uint8/f32 frames [T,3,H,W] with H,W multiples of 28
+    def _frames(self, mm) -> Optional[torch.Tensor]:
+        if not mm:
+            return None
+        data = mm.get("image", None)
+        if data is None:
+            data = mm.get("video", None)
+        if data is None:
+            return None
+        if isinstance(data, (list, tuple)):
+            lim = self.limit_mm.get("image")
+            if lim is not None and len(data) > lim:
+                raise ValueError(f"{len(data)} images exceed limit_mm_per_prompt['image']={lim}")
+            frames = []
+            for im in data:
+                arr = np.asarray(im.convert("RGB") if hasattr(im, "convert") else im)
+                if arr.ndim == 3 and arr.shape[-1] == 3:
+                    arr = arr.transpose(2, 0, 1)
+                frames.append(torch.from_numpy(np.ascontiguousarray(arr)))
+            sizes = {tuple(f.shape[1:]) for f in frames}
+            if len(sizes) != 1:
+                raise NotImplementedError("images of different sizes in one request")
+            data = torch.stack(frames)
+        else:
+            data = torch.as_tensor(np.asarray(data)) if not torch.is_tensor(data) else data
+            if data.dim() == 3:
+                data = data[None]
+        if data.shape[1] != 3 and data.shape[-1] == 3:
+            data = data.permute(0, 3, 1, 2)
+        T, _, H, W = data.shape
+        # the HF image processor resizes every image with smart_resize(factor 28, min/max pixels) -- a no-op for frames
+        # that process_vision_info already sized
+        rh, rw = vp.smart_resize(H, W, 28, self.min_pixels, self.max_pixels)
+        if (rh, rw) != (H, W):
+            data = vp.resize_frames(data, (rh, rw))
+        return data
+
+    def _tokenize(self, prompt: str, n_frames: int, tok_per_frame: int):
+        if n_frames:
+            n_tags = prompt.count(self.IMAGE_PAD)
+            if n_tags != n_frames:
+                raise ValueError(f"prompt has {n_tags} image placeholders but {n_frames} images were given")
+            prompt = prompt.replace(self.IMAGE_PAD, self.IMAGE_PAD * tok_per_frame)
+        ids = self.tokenizer.encode(prompt, add_special_tokens=False) if hasattr(self.tokenizer, "encode") else self.tokenizer(prompt)
+        return list(ids)
+
+    def generate(self, inputs, sampling_params: Optional[SamplingParams] = None, use_tqdm: bool = False):
+        sp = sampling_params or SamplingParams()
+        if isinstance(inputs, dict):
+            inputs = [inputs]
+        results = []
+        for req in inputs:
+            prompt = req["prompt"] if isinstance(req, dict) else str(req)
+            frames = self._frames(req.get("multi_modal_data") if isinstance(req, dict) else None)
+            tpf = 0 if frames is None else (frames.shape[2] // 28) * (frames.shape[3] // 28)
+            ids = self._tokenize(prompt, 0 if frames is None else frames.shape[0], tpf)
+            if len(ids) + sp.max_tokens > self.max_model_len:
+                raise ValueError(f"prompt ({len(ids)}) + max_tokens ({sp.max_tokens}) exceeds max_model_len {self.max_model_len}")
+            greedy = sp.temperature == 0.0
+            stop = list(sp.stop_token_ids) if sp.stop_token_ids else []
+            eos = stop + ([self.cfg.eos_token_id] if self.cfg.eos_token_id is not None else [])
+            out = self.engine.generate([ids], None, frames=frames, max_new_tokens=sp.max_tokens, eos_token_ids=eos,
+                                       pad_token_id=self.cfg.pad_token_id, repetition_penalty=sp.repetition_penalty,
+                                       do_sample=not greedy, temperature=1.0 if greedy else sp.temperature,
+                                       top_p=1.0 if greedy else sp.top_p, num_return_sequences=sp.n,
+                                       seed=self._req if sp.seed is None else sp.seed, return_margins=False)
+            ro = RequestOutput(request_id=str(self._req), prompt=prompt, prompt_token_ids=ids)
+            for i in range(sp.n):
+                toks = out.sequences[i, len(ids):].tolist()
+                reason = "length"
+                for j, t in enumerate(toks):
+                    if t in eos:
+                        toks, reason = toks[:j], "stop"   # vLLM drops the stop token from the text
+                        break
+                ro.outputs.append(CompletionOutput(i, self.tokenizer.decode(toks, skip_special_tokens=True), toks, reason))
+            results.append(ro)
+            self._req += 1
+        return results

@@ -1,0 +1,169 @@
+"""GPU tests of the reference-shaped call surfaces: HF-style generate()/__call__ (R:grpo_trainer.py:581-586,:375),
+vLLM-style LLM.generate (R:eval/inference_example.py:15-29,81), local safetensors loading with hub weight names,
+and one GSPO group-rollout step."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_models as fm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+class StubTokenizer:
+    """Whitespace tokenizer over 'w<ID>' words plus the special tags (no real tokenizer files exist offline)."""
+    specials = {"<|vision_start|>": "vision_start_token_id", "<|image_pad|>": "image_token_id", "<|vision_end|>": "vision_end_token_id"}
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def encode(self, text, add_special_tokens=False):
+        for s in self.specials:
+            text = text.replace(s, f" {s} ")
+        out = []
+        for w in text.split():
+            out.append(self.cfg[self.specials[w]] if w in self.specials else int(w[1:]))
+        return out
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(f"w{int(i)}" for i in ids)
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [self.decode(r) for r in ids.tolist()]
+
+
+def test_hf_facade_generate_and_logits(need_gpu, golden_dir):
+    from open_o3_video_amd.hf_api import GenerationConfigLike, Qwen2_5_VLForConditionalGeneration, Qwen2VLForConditionalGeneration
+    assert Qwen2VLForConditionalGeneration is Qwen2_5_VLForConditionalGeneration
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    model = Qwen2_5_VLForConditionalGeneration.from_state_dict(cfg, fm.make_weights(cfg, 2))
+    assert model.eval() is model and hasattr(model, "warnings_issued") and hasattr(model.config, "_name_or_path")
+    prompt_inputs = dict(input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.ones_like(torch.from_numpy(g["input_ids"])),
+                         pixel_values=torch.from_numpy(g["pixel_values"]), image_grid_thw=torch.from_numpy(g["grid"]))
+    gc = GenerationConfigLike(max_new_tokens=16, do_sample=False, num_return_sequences=1, pad_token_id=cfg["pad_token_id"],
+                              eos_token_id=None)
+    out = model.generate(**prompt_inputs, generation_config=gc)
+    assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g["bf16_ids"])
+    # two prompts (the same one twice) x G=2 -> rows b*G+g, all equal under greedy decoding
+    two = {k: (torch.cat([v, v]) if k != "image_grid_thw" else torch.cat([v, v])) for k, v in prompt_inputs.items()}
+    gc2 = GenerationConfigLike(max_new_tokens=6, do_sample=False, num_return_sequences=2, pad_token_id=cfg["pad_token_id"], eos_token_id=None)
+    out2 = model.generate(**two, generation_config=gc2)
+    assert out2.shape[0] == 4 and all(torch.equal(out2[i], out[0, : out2.shape[1]]) for i in range(4))
+    # forward logits + the reference's log-prob recipe on them
+    lg = model(out, attention_mask=torch.ones_like(out), pixel_values=prompt_inputs["pixel_values"],
+               image_grid_thw=prompt_inputs["image_grid_thw"]).logits
+    assert lg.shape == (1, out.shape[1], cfg["text_config"]["vocab_size"])
+    S = g["input_ids"].shape[1]
+    assert torch.equal(lg[0, S - 1:-1].float().argmax(-1).cpu(), out[0, S:].cpu())  # teacher-forced argmax == greedy ids
+    ref_lp = torch.log_softmax(lg[:, :-1].float(), -1).gather(2, out[:, 1:, None].to(lg.device))[..., 0]
+    lp = model.per_token_logps(out, torch.ones_like(out), prompt_inputs["pixel_values"], prompt_inputs["image_grid_thw"])
+    assert torch.allclose(lp, ref_lp, atol=2e-4, rtol=0)
+    with pytest.raises(ValueError):
+        model.generate(input_ids=prompt_inputs["input_ids"], pixel_values=prompt_inputs["pixel_values"][:-4],
+                       image_grid_thw=prompt_inputs["image_grid_thw"], generation_config=gc)
+
+
+def test_from_pretrained_local_dir_with_hub_names(need_gpu, tmp_path, golden_dir):
+    """config.json + model.safetensors with the hub's weight names (visual.*, model.layers.*) load identically."""
+    from safetensors.torch import save_file
+    from open_o3_video_amd.hf_api import Qwen2_5_VLForConditionalGeneration
+    cfg = fm.tiny_config()
+    W = fm.make_weights(cfg, 0)
+    hub = {}
+    for k, v in W.items():
+        k2 = k.replace("model.visual.", "visual.").replace("model.language_model.", "model.")
+        hub[k2] = v.to(torch.bfloat16).contiguous()
+    flat = dict(cfg["text_config"], **{k: v for k, v in cfg.items() if k != "text_config"})
+    flat["rope_scaling"] = {"type": "mrope", "mrope_section": flat.pop("mrope_section")}
+    (tmp_path / "config.json").write_text(json.dumps(flat))
+    save_file(hub, str(tmp_path / "model.safetensors"))
+    model = Qwen2_5_VLForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16,
+                                                               attn_implementation="flash_attention_2", use_cache=False)
+    g = np.load(os.path.join(golden_dir, "g6_tiny.npz"))
+    out = model.generate(input_ids=torch.from_numpy(g["input_ids"]), pixel_values=torch.from_numpy(g["pixel_values"]),
+                         image_grid_thw=torch.from_numpy(g["grid"]), max_new_tokens=16, do_sample=False, eos_token_id=None,
+                         pad_token_id=cfg["pad_token_id"])
+    assert np.array_equal(out.cpu().numpy(), g["bf16_ids"])
+    with pytest.raises(OSError):
+        Qwen2_5_VLForConditionalGeneration.from_pretrained("Qwen/Qwen2.5-VL-7B-Instruct")  # never downloads
+
+
+def test_vllm_facade(need_gpu, golden_dir):
+    from open_o3_video_amd.vllm_api import LLM, SamplingParams
+    from test_gpu_model import build_engine
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 2))
+    llm = LLM(engine=eng, tokenizer=StubTokenizer(cfg), limit_mm_per_prompt={"image": 32}, max_model_len=4096)
+    # rebuild the prompt text with ONE <|image_pad|> per frame, as the eval scripts do
+    words, ids = [], g["input_ids"][0].tolist()
+    i = 0
+    while i < len(ids):
+        if ids[i] == cfg["image_token_id"]:
+            words.append("<|image_pad|>")
+            while i < len(ids) and ids[i] == cfg["image_token_id"]:
+                i += 1
+            continue
+        words.append({cfg["vision_start_token_id"]: "<|vision_start|>", cfg["vision_end_token_id"]: "<|vision_end|>"}.get(ids[i], f"w{ids[i]}"))
+        i += 1
+    prompt = " ".join(words)
+    frames = torch.from_numpy(g["frames"])
+    sp = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=16, stop_token_ids=[])
+    outs = llm.generate([{"prompt": prompt, "multi_modal_data": {"image": frames}}], sampling_params=sp)
+    exp = g["bf16_ids_rp105"][0, g["input_ids"].shape[1]:].tolist()
+    assert outs[0].prompt_token_ids == ids
+    assert outs[0].outputs[0].token_ids == exp and outs[0].outputs[0].text == " ".join(f"w{t}" for t in exp)
+    # float frames (what process_vision_info returns for a video) and a list of HWC arrays give the same tokens
+    o2 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames.float()}}, sp)
+    o3 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": [f.permute(1, 2, 0).numpy() for f in frames]}}, sp)
+    assert o2[0].outputs[0].token_ids == exp and o3[0].outputs[0].token_ids == exp
+    # stop token: generation ends there and the stop token is not part of the text
+    assert exp[3] not in exp[:3]
+    sp2 = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=16, stop_token_ids=[exp[3]])
+    o4 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}}, sp2)[0].outputs[0]
+    assert o4.token_ids == exp[:3] and o4.finish_reason == "stop"
+    with pytest.raises(ValueError):
+        llm.generate({"prompt": prompt.replace("<|image_pad|>", "", 1), "multi_modal_data": {"image": frames}}, sp)
+    # sampled request with n completions
+    o5 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}},
+                      SamplingParams(temperature=0.7, top_p=0.9, repetition_penalty=1.05, max_tokens=8, n=3, seed=3))
+    assert len(o5[0].outputs) == 3
+
+
+def test_group_rollout_step(need_gpu, golden_dir):
+    from open_o3_video_amd import rewards, rollout
+    from open_o3_video_amd.hf_api import Qwen2_5_VLForConditionalGeneration
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    model = Qwen2_5_VLForConditionalGeneration.from_state_dict(cfg, fm.make_weights(cfg, 2))
+    ref = Qwen2_5_VLForConditionalGeneration.from_state_dict(cfg, fm.make_weights(cfg, 9))
+    tok = StubTokenizer(cfg)
+    G, T = 4, 10
+    gr = rollout.GroupRollout(model, [rewards.format_reward, lambda completions, **kw: [float(len(c[0]["content"]) % 3) for c in completions]],
+                              tok.batch_decode, eos_token_id=cfg["eos_token_id"], pad_token_id=cfg["pad_token_id"], ref_model=ref,
+                              num_generations=G, max_completion_length=T)
+    ids = torch.from_numpy(g["input_ids"])
+    res = gr.step(dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=torch.from_numpy(g["pixel_values"]),
+                       image_grid_thw=torch.from_numpy(g["grid"])), {"prompt": "p", "task": "temporal-spatial free-form QA"})
+    S = ids.shape[1]
+    assert res.prompt_completion_ids.shape[0] == G and res.completion_ids.shape[1] <= T
+    assert torch.equal(res.prompt_completion_ids[:, :S].cpu(), ids.repeat(G, 1))
+    assert res.per_token_logps.shape == res.completion_ids.shape == res.ref_per_token_logps.shape
+    assert (res.per_token_logps <= 0).all() and (res.per_token_kl >= 0).all()
+    assert res.rewards_per_func.shape == (G, 2) and torch.equal(res.rewards, res.rewards_per_func.sum(1))
+    assert torch.isfinite(res.loss) and set(res.metrics) >= {"completion_length", "reward", "reward_std", "kl", "all_wrong", "all_correct"}
+    # policy log-probs of the sampled tokens agree with a full forward through the logits facade
+    lg = model(res.prompt_completion_ids, pixel_values=torch.from_numpy(g["pixel_values"]).repeat(G, 1),
+               image_grid_thw=torch.from_numpy(g["grid"]).repeat(G, 1)).logits
+    ref_lp = torch.log_softmax(lg[:, :-1].float(), -1).gather(2, res.prompt_completion_ids[:, 1:, None].to(lg.device))[..., 0][:, S - 1:]
+    assert torch.allclose(res.per_token_logps, ref_lp, atol=2e-4, rtol=0)

@@ -1,0 +1,100 @@
+"""CPU tests: GSPO math vs the oracle transcription, data-parallel sharding helpers, and the N>1 path over a real
+2-process gloo world (the rollout metrics all_gather and the sharded eval harness)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from open_o3_video_amd import dist as od
+from open_o3_video_amd import rollout
+from oracle import gspo_ref
+
+
+def test_completion_mask_matches_reference_rule():
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 7, (16, 12), generator=g)
+    ids[3] = 1  # no EOS at all
+    ids[4, 0] = 5
+    assert torch.equal(rollout.completion_mask(ids, 5), gspo_ref.eos_mask(ids, 5))
+    m = rollout.completion_mask(torch.tensor([[1, 5, 2, 5], [1, 2, 3, 4], [5, 5, 5, 5]]), 5)
+    assert m.tolist() == [[1, 1, 0, 0], [1, 1, 1, 1], [1, 0, 0, 0]]
+
+
+@pytest.mark.parametrize("gspo", [True, False])
+def test_gspo_loss_matches_oracle(gspo):
+    g = torch.Generator().manual_seed(1)
+    G, T = 4, 9
+    lp = -torch.rand(2 * G, T, generator=g) * 3
+    ref = lp + 0.3 * torch.randn(2 * G, T, generator=g)
+    ref[0, 0] = lp[0, 0] + 50  # exercises the clamp
+    rewards = torch.rand(2 * G, generator=g) * 3
+    rewards[G:] = 1.0  # zero-variance group -> advantages 0 (std + 1e-4)
+    mask = gspo_ref.eos_mask(torch.randint(0, 6, (2 * G, T), generator=g), 5)
+    mask[1] = 0  # empty completion: clamp(min=1) path
+    loss_ref, adv_ref, kl_ref, std_ref = gspo_ref.loss_and_parts(lp, ref, rewards, mask, G, gspo=gspo)
+    adv, std = rollout.group_advantages(rewards, G)
+    assert torch.equal(adv, adv_ref) and torch.equal(std, std_ref)
+    assert torch.equal(rollout.per_token_kl(ref, lp), kl_ref)
+    loss = rollout.gspo_loss(lp, lp, ref, adv, mask, gspo=gspo)
+    assert torch.allclose(loss, loss_ref, rtol=0, atol=1e-7)
+    assert (adv[G:] == 0).all()
+
+
+def test_chunking():
+    for n in (0, 1, 7, 8, 9, 100):
+        for w in (1, 2, 3, 8):
+            cov = sorted(i for r in range(w) for i in od.contiguous_chunk(n, r, w))
+            assert cov == list(range(n))
+            cov = sorted(i for r in range(w) for i in od.strided_chunk(n, r, w))
+            assert cov == list(range(n))
+    assert list(od.contiguous_chunk(10, 0, 4)) == [0, 1, 2] and list(od.contiguous_chunk(10, 3, 4)) == [8, 9]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    r, w = od.init("gloo")
+    assert (r, w) == (rank, world)
+    # sharded eval: every rank gets all results in order
+    res = od.run_data_parallel(list(range(11)), lambda x: x * x + rank * 0, policy="contiguous")
+    res2 = od.run_data_parallel(list(range(11)), lambda x: -x, policy="strided")
+    # rollout metrics record: rank r contributes rewards r+1
+    G, nf = 4, 7
+    rr = rollout.RolloutResult(None, None, torch.ones(G, 5, dtype=torch.int32), None, None, torch.full((G, 5), 0.5),
+                               torch.full((G, nf), float(rank + 1)), torch.full((G,), float(nf * (rank + 1))), None, None, [])
+    gr = rollout.GroupRollout(None, [lambda **k: 0] * nf, None, 0, 0, num_generations=G)
+    metrics = gr.gather_metrics(rr, torch.full((G,), 0.25 * (rank + 1)))
+    gathered = od.all_gather_records(torch.full((2, 3), float(rank)))
+    q.put((rank, res, res2, metrics, gathered.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo_world():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in ps], key=lambda o: o[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, res2, metrics, gathered in outs:
+        assert res == [x * x for x in range(11)]
+        assert res2 == [-x for x in range(11)]
+        assert gathered == [[0.0] * 3] * 2 + [[1.0] * 3] * 2
+        assert metrics["reward"] == pytest.approx((7 * 1 + 7 * 2) / 2)
+        assert metrics["completion_length"] == 5.0 and metrics["kl"] == pytest.approx(0.5)
+        assert metrics["reward_std"] == pytest.approx(0.375)
+        assert metrics["all_wrong"] == 0.0 and metrics["all_correct"] == 1.0
