@@ -189,48 +189,6 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     const int rg = wave / KS, ks = wave % KS;
     const int nch = K >> 3;
 
-    if (NORM) {
-        // ---- block-wide RMSNorm of x into LDS: xs[m][k] = bf16(w[k] * bf16(x[m][k] * rstd[m]))
-        float ss[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) ss[m] = 0.f;
-        for (int c = threadIdx.x; c < nch; c += 256) {
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ss[m] = fmaf(bf_lo(v[j]), bf_lo(v[j]), ss[m]);
-                    ss[m] = fmaf(bf_hi(v[j]), bf_hi(v[j]), ss[m]);
-                }
-            }
-        }
-        float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 4 * R * M * 4);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            ss[m] = wave_sum(ss[m]);
-            if (lane == 0) red[wave * M + m] = ss[m];
-        }
-        __syncthreads();
-        float rstd[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-            rstd[m] = 1.0f / sqrtf((red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m]) / (float)K + eps);
-        for (int c = threadIdx.x; c < nch; c += 256) {
-            const u32x4 wv = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
-                u32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    o[j] = pack_bf2(bf_lo(wv[j]) * rbf(bf_lo(v[j]) * rstd[m]), bf_hi(wv[j]) * rbf(bf_hi(v[j]) * rstd[m]));
-                *reinterpret_cast<u32x4*>(smem + ((size_t)m * K + (size_t)c * 8) * 2) = o;
-            }
-        }
-        __syncthreads();
-    }
-
     // ---- rows of this wave.  SWIGLU: R/2 output columns = R/2 (gate,up) row pairs of the 16-row-interleaved weight
     const int grp = blockIdx.x * RG + rg;
     int rows[R];
@@ -257,12 +215,6 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         const int rr = rows[r] < N ? rows[r] : N - 1;  // tail rows re-read a valid row, never stored
         wp[r] = reinterpret_cast<const u32x4*>(W + (size_t)rr * ldw);
     }
-    float acc[R][M];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-
     // K-slice in whole 64-chunk steps
     const int steps = (nch + 63) >> 6;
     const int sps = (steps + KS - 1) / KS;
@@ -270,8 +222,10 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     int c_end = c_begin + sps * 64;
     c_end = c_end < nch ? c_end : nch;
     constexpr int U = (R >= 4) ? 2 : 4;
-    for (int c0 = c_begin; c0 < c_end; c0 += 64 * U) {
-        u32x4 wv[U][R], xv[U][M];
+
+    // weight loads of one trip (U steps x R rows, 16 B per lane each): issued as early as possible
+    u32x4 wv[U][R];
+    auto load_w = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + u * 64 + lane;
@@ -282,6 +236,105 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
                 wv[u][r] = __builtin_nontemporal_load(wp[r] + cc);
                 if (!in) wv[u][r] = (u32x4){0, 0, 0, 0};
             }
+        }
+    };
+
+    if (NORM) {
+        // ---- block-wide RMSNorm of x into LDS: xs[m][k] = bf16(w[k] * bf16(x[m][k] * rstd[m])).
+        // x (a few KiB, L2-resident) is requested first, then the first trip of weight loads, so that the
+        // HBM latency of the weights runs under the norm instead of after it.
+        constexpr int XC = 2;                        // x chunks per thread kept in registers (K <= 4096)
+        const bool small = (nch <= XC * 256) && (M <= 4);
+        u32x4 xr[XC][M <= 4 ? M : 1];
+        float ss[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) ss[m] = 0.f;
+        if (small) {
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                const int c = threadIdx.x + i * 256;
+#pragma unroll
+                for (int m = 0; m < (M <= 4 ? M : 1); ++m)
+                    xr[i][m] = c < nch ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+            }
+        }
+        if (c_begin < c_end) load_w(c_begin);
+        if (small) {
+#pragma unroll
+            for (int i = 0; i < XC; ++i)
+#pragma unroll
+                for (int m = 0; m < (M <= 4 ? M : 1); ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ss[m] = fmaf(bf_lo(xr[i][m][j]), bf_lo(xr[i][m][j]), ss[m]);
+                        ss[m] = fmaf(bf_hi(xr[i][m][j]), bf_hi(xr[i][m][j]), ss[m]);
+                    }
+        } else {
+            for (int c = threadIdx.x; c < nch; c += 256) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ss[m] = fmaf(bf_lo(v[j]), bf_lo(v[j]), ss[m]);
+                        ss[m] = fmaf(bf_hi(v[j]), bf_hi(v[j]), ss[m]);
+                    }
+                }
+            }
+        }
+        float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 4 * R * M * 4);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            ss[m] = wave_sum(ss[m]);
+            if (lane == 0) red[wave * M + m] = ss[m];
+        }
+        __syncthreads();
+        float rstd[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            rstd[m] = 1.0f / sqrtf((red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m]) / (float)K + eps);
+        auto norm_store = [&](int c, int m, const u32x4& v, const u32x4& wn) {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack_bf2(bf_lo(wn[j]) * rbf(bf_lo(v[j]) * rstd[m]), bf_hi(wn[j]) * rbf(bf_hi(v[j]) * rstd[m]));
+            *reinterpret_cast<u32x4*>(smem + ((size_t)m * K + (size_t)c * 8) * 2) = o;
+        };
+        if (small) {
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                const int c = threadIdx.x + i * 256;
+                if (c < nch) {
+                    const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
+#pragma unroll
+                    for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[i][m], wn);
+                }
+            }
+        } else {
+            for (int c = threadIdx.x; c < nch; c += 256) {
+                const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                    norm_store(c, m, *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8), wn);
+            }
+        }
+        __syncthreads();
+    } else {
+        if (c_begin < c_end) load_w(c_begin);
+    }
+
+    float acc[R][M];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+
+    for (int c0 = c_begin; c0 < c_end; c0 += 64 * U) {
+        u32x4 xv[U][M];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const int cc = c < c_end ? c : c_begin;  // out-of-range lanes meet zeroed weights
 #pragma unroll
             for (int m = 0; m < M; ++m)
                 xv[u][m] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + (size_t)cc * 8) * 2)
@@ -293,6 +346,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int m = 0; m < M; ++m) fma8(wv[u][r], xv[u][m], acc[r][m]);
+        if (c0 + 64 * U < c_end) load_w(c0 + 64 * U);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)

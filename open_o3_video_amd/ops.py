@@ -51,8 +51,9 @@ def attn_decode(q, kc, vc, k_lo, ctx, nsplit, scale):
     B, Hq, D = q.shape
     _, Hkv, Tmax, _ = kc.shape
     out = torch.empty_like(q)
-    po = torch.empty(B * Hq * nsplit * D, dtype=torch.float32, device=q.device)
-    pm = torch.empty(B * Hq * nsplit * 2, dtype=torch.float32, device=q.device)
+    ns = abs(nsplit)  # negative nsplit selects the scalar (non-MFMA) kernel
+    po = torch.empty(B * Hq * ns * D, dtype=torch.float32, device=q.device)
+    pm = torch.empty(B * Hq * ns * 2, dtype=torch.float32, device=q.device)
     _lib.call("o3v_attn_decode", _p(q), _p(kc), _p(vc), _p(out), _p(po), _p(pm), _p(k_lo), B, Hq, Hkv, D, ctx, Tmax, nsplit,
               float(scale), _s())
     return out

@@ -335,7 +335,11 @@ def test_attn_online_softmax_rescale_branch(dev):
 
 @pytest.mark.parametrize("B,Hq,Hkv,D,ctx,pads,nsplit", [(1, 28, 4, 128, 4700, [0], 64), (2, 14, 2, 128, 333, [0, 40], 5),
                                                          (3, 4, 2, 32, 17, [0, 3, 16], 1), (2, 16, 2, 128, 64, [0, 0], 3),
-                                                         (8, 4, 4, 64, 200, [0] * 8, 4)])
+                                                         (8, 4, 4, 64, 200, [0] * 8, 4),
+                                                         # negative nsplit: scalar kernel for head_dim 128 (MFMA kernel otherwise)
+                                                         (1, 28, 4, 128, 4700, [0], -36), (2, 14, 2, 128, 333, [0, 40], -5),
+                                                         (1, 28, 4, 128, 5001, [17], 37), (4, 7, 1, 128, 1, [0] * 4, 2),
+                                                         (2, 8, 1, 128, 130, [129, 0], 1)])
 def test_attn_decode(dev, B, Hq, Hkv, D, ctx, pads, nsplit):
     from open_o3_video_amd import ops
     Tmax = ctx + 11
