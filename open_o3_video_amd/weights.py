@@ -191,7 +191,7 @@ def getter_from_safetensors_dir(path: str):
     return get
 
 
-def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02):
+def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02, head_std=None):
     """Seeded random bf16 weights at the model's true dimensions, generated on the device (benchmarks only:
     there are no checkpoints offline; throughput does not depend on weight values)."""
     gen = torch.Generator(device=device).manual_seed(seed)
@@ -229,6 +229,6 @@ def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02):
                 or name.endswith("norm.weight") or name.endswith("ln_q.weight"):
             return torch.ones(shape, device=device, dtype=torch.bfloat16)
         t = torch.empty(shape, device=device, dtype=torch.bfloat16)
-        t.normal_(0.0, std, generator=gen)
+        t.normal_(0.0, head_std if (head_std is not None and name == "lm_head.weight") else std, generator=gen)
         return t
     return get
