@@ -62,6 +62,10 @@ int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, o3
 int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
                  const float* std3, o3v_stream_t stream);
 
+/* Cache prefetch hint: stream `bytes` at `ptr` through `blocks` workgroups (result discarded) so the next reader finds
+ * them in L2 / Infinity Cache; meant for a side stream beside a latency-bound kernel. */
+int o3v_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, o3v_stream_t stream);
+
 /* ---- GEMMs ------------------------------------------------------------------------------------------------ */
 /* nn.Linear: out[M,N] = epi(A[M,K] . W[N,K]^T + bias); K % 64 == 0.  MFMA path (ViT, merger, prefill). */
 int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
@@ -181,6 +185,8 @@ typedef struct {
     float *part_o, *part_ml;     /* decode-attention split buffers */
     float *sample_scratch;       /* f32 [B,vocab] when sampling, f32 [B,256] for greedy */
     void *workspace; size_t ws_bytes;
+    o3v_stream_t side_stream;    /* optional: weight prefetch runs here beside the decode attention (NULL = off) */
+    size_t prefetch_bytes;       /* bytes of the next projections' weights to pull on-die per layer */
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

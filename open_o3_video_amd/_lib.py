@@ -43,7 +43,7 @@ class DecodeState(C.Structure):
                 ("x", vp), ("kcache", vp), ("vcache", vp), ("cosT", vp), ("sinT", vp), ("logits", vp), ("seen", vp),
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
-                ("ws_bytes", sz)]
+                ("ws_bytes", sz), ("side_stream", vp), ("prefetch_bytes", sz)]
 
 
 # name -> argtypes (return type int unless listed in _RET)
@@ -58,6 +58,7 @@ SIGNATURES = {
     "o3v_embed_tokens": [vp, vp, vp, i32, i32, vp],
     "o3v_cast_pad_f32_bf16": [vp, vp, i32, i32, i32, vp],
     "o3v_patchify": [vp, i32, vp, i32, i32, i32, i32, fp, fp, vp],
+    "o3v_prefetch": [vp, sz, i32, vp, vp],
     "o3v_gemm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],

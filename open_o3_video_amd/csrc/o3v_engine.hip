@@ -194,6 +194,17 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         return O3V_ERR_WORKSPACE;
     const float scale = 1.0f / sqrtf((float)D);
     const size_t layer_stride = (size_t)B * Hkv * st->Tmax * D * 2;
+    // optional side stream: while the latency-bound attention of layer l runs (HBM nearly idle), pull the weights the
+    // next two projections will stream (o_proj, head of gate/up) into the Infinity Cache
+    static hipEvent_t ev_ring[8];
+    static bool ev_init = false;
+    if (st->side_stream && !ev_init) {
+        for (auto& e : ev_ring)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return O3V_ERR_LAUNCH;
+        ev_init = true;
+    }
+    int ev_i = 0;
+    const size_t o_bytes = (size_t)H * QD * 2, gu_bytes = (size_t)2 * I * H * 2;
     for (int i = 0; i < n_steps; ++i) {
         const int step = step0 + i;
         if (st->do_sample)
@@ -213,6 +224,16 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             char* vc = (char*)st->vcache + l * layer_stride;
             TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
                                        st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            if (st->side_stream && st->prefetch_bytes) {
+                hipEvent_t ev = ev_ring[ev_i++ & 7];
+                if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
+                    return O3V_ERR_LAUNCH;
+                const size_t pb = st->prefetch_bytes;
+                TRY(o3v_prefetch(lw.o_w, pb < o_bytes ? pb : o_bytes, 48, st->part_ml, st->side_stream));
+                if (pb > o_bytes)
+                    TRY(o3v_prefetch(lw.gu_w, (pb - o_bytes) < gu_bytes ? (pb - o_bytes) : gu_bytes, 48, st->part_ml,
+                                     st->side_stream));
+            }
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
                                 st->Tmax, st->nsplit, scale, s));
             TRY(o3v_gemv_bf16(w.att, lw.o_w, nullptr, st->x, st->x, B, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));

@@ -451,7 +451,7 @@ int launch_gemv(const GemvArgs& a) {
                 a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra)
     switch (a.epi) {
         case EPI_QKVROPE:
-            if (R != 2 || !NORM) return O3V_ERR_ARG;
+            if (R != 2 || !NORM) return O3V_ERR_ARG;  // the rotary pair (j, j+D/2) is the wave's two rows
             if constexpr (R == 2 && NORM) O3V_GV(EPI_QKVROPE);
             break;
         case EPI_NONE: O3V_GV(EPI_NONE); break;
@@ -464,20 +464,36 @@ int launch_gemv(const GemvArgs& a) {
     return O3V_OK;
 }
 
+#ifdef O3V_TUNE
+static int g_tune_R = 0, g_tune_KS = 0;  // tuning build only (tools/tune_gemv.py): force one decomposition
+extern "C" void o3v_gemv_tune(int R, int KS) {
+    g_tune_R = R;
+    g_tune_KS = KS;
+}
+#endif
+
 template <int M, bool NORM>
 int launch_gemv_m(const GemvArgs& a) {
+#ifdef O3V_TUNE
+    if (g_tune_R) {
+#define O3V_T(RR, KK) if (g_tune_R == RR && g_tune_KS == KK) return launch_gemv<M, RR, KK, NORM>(a)
+        O3V_T(2, 1); O3V_T(2, 2); O3V_T(2, 4); O3V_T(4, 1); O3V_T(4, 2); O3V_T(4, 4); O3V_T(8, 1); O3V_T(8, 2);
+#undef O3V_T
+        return O3V_ERR_ARG;
+    }
+#endif
     // Decomposition: enough waves to keep >= 32 KiB of weight loads in flight per CU, whole 512-k steps per wave.
     const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
     const int steps = (a.K / 8 + 63) / 64;
-    if (a.epi == EPI_QKVROPE) return launch_gemv<M, 2, 2, NORM>(a);
+    // decompositions chosen by interleaved A/B on MI355X (tools/tune_gemv.py, profiles/r01_gemv_tune.txt)
+    if (a.epi == EPI_QKVROPE) return launch_gemv<M, 2, 1, NORM>(a);
     if (a.epi == EPI_SWIGLU) {
         if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM>(a);  // 2 (gate,up) pairs per wave
         return launch_gemv<M, 2, 1, NORM>(a);
     }
     if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM>(a);     // lm_head
-    if (steps >= 16) return launch_gemv<M, 2, 4, NORM>(a);                 // long K (down_proj): split K over the 4 waves
-    if (steps >= 6 && outs <= 8192) return launch_gemv<M, 2, 2, NORM>(a);  // o_proj / qkv
-    return launch_gemv<M, 2, 1, NORM>(a);
+    if (steps >= 16) return launch_gemv<M, 2, 2, NORM>(a);                 // long K (down_proj): split K over wave pairs
+    return launch_gemv<M, 2, 1, NORM>(a);                                  // o_proj / qkv
 }
 
 }  // namespace
@@ -521,6 +537,7 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
 #define O3V_M(MM) rc = norm_w ? launch_gemv_m<MM, true>(a) : launch_gemv_m<MM, false>(a)
     switch (M) {
         case 1: O3V_M(1); break;
+#ifndef O3V_TUNE
         case 2: O3V_M(2); break;
         case 3: O3V_M(3); break;
         case 4: O3V_M(4); break;
@@ -528,6 +545,9 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
         case 6: O3V_M(6); break;
         case 7: O3V_M(7); break;
         default: O3V_M(8); break;
+#else
+        default: return O3V_ERR_SHAPE;
+#endif
     }
 #undef O3V_M
     if (rc != O3V_OK) return rc;

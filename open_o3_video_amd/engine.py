@@ -58,6 +58,10 @@ class O3VEngine:
         self.clip_mean = (C.c_float * 3)(*CLIP_MEAN)   # host arrays (read by the launcher, passed by value)
         self.clip_std = (C.c_float * 3)(*CLIP_STD)
         self._vit_plan_cache = {}
+        # side stream for the weight prefetch beside the decode attention (O3V_PREFETCH_MB=0 disables)
+        import os
+        self.prefetch_bytes = int(float(os.environ.get("O3V_PREFETCH_MB", "0")) * 1e6)
+        self.side_stream = torch.cuda.Stream(device=self.dev) if self.prefetch_bytes > 0 else None
 
     # ------------------------------------------------------------------------------------------ vision
     def _vit_plan(self, grid_thw):
@@ -279,7 +283,8 @@ class O3VEngine:
                               eos_ids=eos.data_ptr(), k_lo=k_lo.data_ptr(), row_id=rid.data_ptr(),
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
                               sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
-                              ws_bytes=nbytes)
+                              ws_bytes=nbytes, side_stream=0 if self.side_stream is None else self.side_stream.cuda_stream,
+                              prefetch_bytes=self.prefetch_bytes)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
         use_eos = len(eos_token_ids) > 0

@@ -127,6 +127,7 @@ def test_vllm_facade(need_gpu, golden_dir):
     o2 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames.float()}}, sp)
     o3 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": [f.permute(1, 2, 0).numpy() for f in frames]}}, sp)
     assert o2[0].outputs[0].token_ids == exp and o3[0].outputs[0].token_ids == exp
+    assert llm.vis_cache_hits >= 1  # identical uint8 frames were encoded once (cross-prompt visual reuse)
     # stop token: generation ends there and the stop token is not part of the text
     assert exp[3] not in exp[:3]
     sp2 = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=16, stop_token_ids=[exp[3]])
