@@ -163,12 +163,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 //     fused here with its two bf16 rounding points, which removes one launch per projection.
 //   * the weights stream from HBM exactly once.
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// 8 bf16 x 8 bf16 -> fp32 accumulate with v_dot2c_f32_bf16 (2 MACs per instruction on the packed pairs, no unpacking):
+// 4 VALU instructions per 16-byte chunk pair instead of 24, which keeps the M = 8 (group rollout) GEMV HBM-bound.
 __device__ __forceinline__ void fma8(const u32x4& w, const u32x4& x, float& acc) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        acc = fmaf(bf_lo(w[j]), bf_lo(x[j]), acc);
-        acc = fmaf(bf_hi(w[j]), bf_hi(x[j]), acc);
-    }
+    // (element-wise locals: bit_cast applied directly to `w[j]` of a vector reference is mis-lowered by hipcc 7.2 --
+    // all four j read element 0)
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w0), __builtin_bit_cast(bf16x2_t, x0), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w1), __builtin_bit_cast(bf16x2_t, x1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w2), __builtin_bit_cast(bf16x2_t, x2), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w3), __builtin_bit_cast(bf16x2_t, x3), acc, false);
 }
 
 struct RopeArgs {  // EPI_QKVROPE destinations (one token per row m, cache slot `slot`, table row m*cs_stride+cs_off)

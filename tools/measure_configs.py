@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Measure the secondary BASELINE.json configs on one GPU (7B dims, random weights): EVAL-RES, G=8 group rollout,
+256-frame long video.  Prints one JSON line per config."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import build_prompt  # noqa: E402
+from open_o3_video_amd.config import O3VConfig, qwen25vl_7b_dict  # noqa: E402
+from open_o3_video_amd.engine import O3VEngine  # noqa: E402
+from open_o3_video_amd.weights import DeviceWeights, random_getter  # noqa: E402
+
+cfg = O3VConfig.from_dict(qwen25vl_7b_dict())
+dev = torch.device("cuda")
+eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
+which = sys.argv[1:] or ["eval", "rollout", "long"]
+
+
+def run(tag, frames_n, H, W, S_target, T, **kw):
+    tpf = (H // 28) * (W // 28)
+    ids = build_prompt(cfg, frames_n, tpf, S_target)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (frames_n, 3, H, W), generator=g, dtype=torch.uint8, device=dev)
+    eng.generate([ids], None, frames=frames, max_new_tokens=8, **kw)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = eng.generate([ids], None, frames=frames, max_new_tokens=T, return_margins=False, sync_timings=True, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rows = out.sequences.shape[0]
+    print(json.dumps({"config": tag, "S": len(ids), "rows": rows, "new_tokens": T, "wall_s": round(dt, 3),
+                      "tokens_per_s": round(rows * T / dt, 1), "stage_ms": {k: round(v, 1) for k, v in out.timings.items()},
+                      "decode_ms_per_step": round(out.timings["decode_ms"] / T, 3)}), flush=True)
+
+
+if "eval" in which:
+    run("EVAL-RES 32x364x644 greedy B=1", 32, 364, 644, 10218, 256, repetition_penalty=1.05)
+if "rollout" in which:
+    for G in (2, 4, 8):
+        run(f"rollout G={G} sampled top_p=0.95 (TRAIN-RES)", 32, 224, 420, 4490, 256, num_return_sequences=G, do_sample=True,
+            top_p=0.95, temperature=1.0, seed=1)
+if "long" in which:
+    run("LONG 256x224x224 greedy B=1", 256, 224, 224, 256 * (64 + 15) + 170, 128, repetition_penalty=1.05)
