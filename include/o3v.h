@@ -82,9 +82,14 @@ int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void*
 
 /* Decode q/k/v projection fully fused: RMSNorm -> Linear(+bias) -> M-RoPE -> q to qout[M,Hq,D], k,v appended to the
  * cache [M,Hkv,Tmax,D] at `slot` (TF:733-736, :636-664); cos/sin row of sequence m = m*cs_stride_row + cs_off. */
-int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* bias, int M, int K,
-                           int ldx, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache, int slot,
-                           int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);
+int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* Wp, const void* bias,
+                           int M, int K, int ldx, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache,
+                           int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);
+/* Decode nn.Linear with both weight images: W row-major [N,K] (M == 1) and Wp = the same weights in MFMA-fragment-major
+ * order [N/16][K/32][64][8] (2 <= M <= 8, group rollout); norm_w (fused RMSNorm) and Wp may be NULL. */
+int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* W, const void* Wp, const void* bias,
+                      const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
+                      o3v_stream_t stream);
 
 /* ---- attention ---------------------------------------------------------------------------------------------- */
 /* tiles: int32[n_tiles][8] = {q_row0, q_rows, k_row0, k_len, causal_off, k_lo, batch, 0}.
@@ -136,6 +141,8 @@ typedef struct {
     const void* o_w;             /* [H, Hq*D] */
     const void* gu_w;            /* packed gate/up [2*I, H] */
     const void* down_w;          /* [H, I] */
+    /* optional MFMA-fragment-major copies of the four matrices for the M >= 2 decode path (NULL = row-major only) */
+    const void *qkv_wp, *o_wp, *gu_wp, *down_wp;
 } o3v_llm_layer_w;
 
 typedef struct {
@@ -145,6 +152,7 @@ typedef struct {
     const o3v_llm_layer_w* layer;/* [layers] */
     const void* final_norm;      /* [H] */
     const void* lm_head;         /* [vocab, H] (== embed when tied) */
+    const void* lm_head_p;       /* optional fragment-major copy of lm_head */
 } o3v_llm_desc;
 
 size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P);

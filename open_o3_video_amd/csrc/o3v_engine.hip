@@ -165,8 +165,8 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
     if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
-        return o3v_gemv_norm_bf16(x, d->final_norm, d->rms_eps, d->lm_head, nullptr, nullptr, logits, rows, d->vocab, H, ldx, H,
-                                  d->vocab, 0, O3V_EPI_NONE, s);
+        return o3v_linear_decode(x, d->final_norm, d->rms_eps, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows,
+                                 d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
     TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
     for (int r0 = 0; r0 < rows;) {
         // GEMV groups of <= 8 rows for small row counts; one MFMA GEMM otherwise
@@ -222,8 +222,8 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
-            TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
-                                       st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
+                                       kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
             if (st->side_stream && st->prefetch_bytes) {
                 hipEvent_t ev = ev_ring[ev_i++ & 7];
                 if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
@@ -236,10 +236,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             }
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
                                 st->Tmax, st->nsplit, scale, s));
-            TRY(o3v_gemv_bf16(w.att, lw.o_w, nullptr, st->x, st->x, B, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
-            TRY(o3v_gemv_norm_bf16(st->x, lw.ln2, d->rms_eps, lw.gu_w, nullptr, nullptr, w.mlp, B, 2 * I, H, H, H, I, 0,
-                                   O3V_EPI_SWIGLU, s));
-            TRY(o3v_gemv_bf16(w.mlp, lw.down_w, nullptr, st->x, st->x, B, H, I, I, I, H, H, O3V_EPI_RESIDUAL, s));
+            TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H,
+                                  O3V_EPI_RESIDUAL, s));
+            TRY(o3v_linear_decode(st->x, lw.ln2, d->rms_eps, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
+                                  O3V_EPI_SWIGLU, s));
+            TRY(o3v_linear_decode(w.mlp, nullptr, 0.f, lw.down_w, lw.down_wp, nullptr, st->x, st->x, B, H, I, I, H, H,
+                                  O3V_EPI_RESIDUAL, s));
         }
         TRY(o3v_llm_head(d, st->x, H, B, w.normed, st->logits, s));
     }

@@ -436,6 +436,208 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM on the matrix cores for 2 <= M <= 16 rows (group rollout: G completions decode together).  The
+// scalar GEMV above is VALU/LDS-bound beyond M ~ 2 (M*R dot products per weight chunk); here one
+// v_mfma_f32_16x16x32_bf16 multiplies 16 weight rows x 32 k against all M rows of x at once:
+//   A = W[16 rows][32 k]  (lane (row = lane&15, g = lane>>4) loads 16 B at W[row][k0 + 8g], straight from global)
+//   B = x^T[32 k][16 cols] (lane (m = lane&15, g) reads x[m][k0 + 8g..]; rows m >= M are zero)
+//   C[row][m]: lane (m = lane&15) holds rows 4g..4g+3 -> bias / residual / SwiGLU / RoPE epilogues are lane-local.
+// A wave owns RB row blocks (2 for SwiGLU: the gate and up blocks of the same 16 columns; 2 for the rotary pair
+// blocks j and j + D/2), the 4 waves of a block either take 4 different row groups (KS = 1) or split K (KS = 4).
+// NORM: RMSNorm of x fused, normalised rows kept in LDS with a 16-byte row skew (conflict-free ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool NORM, int KS, bool PACKED>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                        const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                        bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
+                                                        float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
+                                                        RopeArgs ra) {
+    constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
+    constexpr int RG = 4 / KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M x (K*2+16)] [KS>1: 4 x RB x 64 x 4 f32] [red]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rg = wave / KS, ks = wave % KS;
+    const int xstride = K * 2 + 16;
+    const size_t norm_bytes = NORM ? (size_t)M * xstride : 0;  // only the M live rows are staged
+
+    // ---- row blocks of this wave
+    const int grp = blockIdx.x * RG + rg;
+    int rb0[RB];
+    if (EPI == EPI_SWIGLU) {
+        rb0[0] = grp * 32;            // gate rows of output columns 16*grp .. 16*grp+15
+        rb0[RB - 1] = grp * 32 + 16;  // their up rows
+    } else if (EPI == EPI_QKVROPE) {
+        const int bph = ra.D / 32;    // 16-row blocks per half head
+        const int head = grp / bph, jb = grp % bph;
+        rb0[0] = head * ra.D + jb * 16;
+        rb0[RB - 1] = rb0[0] + ra.D / 2;
+    } else {
+        rb0[0] = grp * 16;
+    }
+    const int nks = K >> 5;                      // 32-wide k-steps
+    // PACKED: W is the fragment-major image [N/16][K/32][64 lanes][8] (weights.py pack_mfma_fragments): the A fragment
+    // of (row block, k-step) is one contiguous KiB, so the wave streams exactly like the scalar GEMV does.
+    const bf16_t* wrow[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        if (PACKED) {
+            const int blk = (rb0[b] < N ? rb0[b] : 0) >> 4;
+            wrow[b] = W + ((size_t)blk * nks * 64 + lane) * 8;
+        } else {
+            int r = rb0[b] + fr;
+            r = r < N ? r : N - 1;
+            wrow[b] = W + (size_t)r * ldw + fg * 8;
+        }
+    }
+    const int per = (nks + KS - 1) / KS;
+    const int s_begin = ks * per;
+    int s_end = s_begin + per;
+    s_end = s_end < nks ? s_end : nks;
+
+    if (NORM) {
+        // RMSNorm of the M rows into LDS, one wave per row (rows wave, wave+4, ...): wave-level reduction only, a single
+        // block barrier at the end.  Row chunks stay in registers between the two passes when K <= 8 * 512.
+        const int nch = K >> 3;
+        for (int m = wave; m < M; m += 4) {
+            u32x4 xr[8];
+            float ss = 0.f;
+            const bool in_regs = nch <= 8 * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + i * 64;
+                xr[i] = (in_regs && c < nch) ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ss = fmaf(bf_lo(xr[i][j]), bf_lo(xr[i][j]), ss);
+                    ss = fmaf(bf_hi(xr[i][j]), bf_hi(xr[i][j]), ss);
+                }
+            }
+            if (!in_regs) {
+                for (int c = lane; c < nch; c += 64) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ss = fmaf(bf_lo(v[j]), bf_lo(v[j]), ss);
+                        ss = fmaf(bf_hi(v[j]), bf_hi(v[j]), ss);
+                    }
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)K + eps);
+            auto put = [&](int c, const u32x4& v) {
+                const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = pack_bf2(bf_lo(wn[j]) * rbf(bf_lo(v[j]) * rstd), bf_hi(wn[j]) * rbf(bf_hi(v[j]) * rstd));
+                *reinterpret_cast<u32x4*>(smem + (size_t)m * xstride + (size_t)c * 16) = o;
+            };
+            if (in_regs) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < nch) put(c, xr[i]);
+                }
+            } else {
+                for (int c = lane; c < nch; c += 64) put(c, *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8));
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool has_x = fr < M;
+    constexpr int U = 8 / RB;  // 8 KiB of weight loads in flight per wave and trip
+    for (int s0 = s_begin; s0 < s_end; s0 += U) {
+        bf16x8 wf[U][RB], xf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sidx = s0 + u;
+            const int sld = sidx < s_end ? sidx : s_begin;
+            const int kk = sld * 32;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                wf[u][b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow[b] + (PACKED ? (size_t)sld * 512 : (size_t)kk)));
+                if (sidx >= s_end) wf[u][b] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            if (has_x)
+                xf[u] = NORM ? *reinterpret_cast<const bf16x8*>(smem + (size_t)fr * xstride + (size_t)(kk + fg * 8) * 2)
+                             : *reinterpret_cast<const bf16x8*>(X + (size_t)fr * ldx + kk + fg * 8);
+            else
+                xf[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][b], xf[u], acc[b], 0, 0, 0);
+    }
+    if (KS > 1) {
+        f32x4* part = reinterpret_cast<f32x4*>(smem + norm_bytes);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) part[(wave * RB + b) * 64 + lane] = acc[b];
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < KS; ++k2) t += part[((rg * KS + k2) * RB + b) * 64 + lane];
+            acc[b] = t;
+        }
+    }
+    // ---- epilogue: this lane holds C[n = rb0 + 4*fg + r][m = fr]
+    const int m = fr;
+    if (m >= M) return;
+    if (EPI == EPI_SWIGLU) {
+        const int no0 = grp * 16 + fg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int no = no0 + r;
+            if (no >= (N >> 1)) continue;
+            const float bg = bias ? bf2f(bias[rb0[0] + fg * 4 + r]) : 0.f;
+            const float bu = bias ? bf2f(bias[rb0[RB - 1] + fg * 4 + r]) : 0.f;
+            const float g = rbf(acc[0][r] + bg), u = rbf(acc[RB - 1][r] + bu);
+            out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
+        }
+    } else if (EPI == EPI_QKVROPE) {
+        const int half = ra.D >> 1, head = rb0[0] / ra.D, j0 = rb0[0] % ra.D + fg * 4;
+        if (rb0[0] >= N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + r;
+            const float b0 = bias ? bf2f(bias[head * ra.D + j]) : 0.f, b1 = bias ? bf2f(bias[head * ra.D + j + half]) : 0.f;
+            const float v0 = rbf(acc[0][r] + b0), v1 = rbf(acc[RB - 1][r] + b1);
+            if (head >= ra.Hq + ra.Hkv) {
+                bf16_t* dst = ra.vc + (((size_t)m * ra.Hkv + (head - ra.Hq - ra.Hkv)) * ra.Tmax + ra.slot) * ra.D;
+                dst[j] = f2bf(v0);
+                dst[j + half] = f2bf(v1);
+                continue;
+            }
+            const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + j;
+            const float c = bf2f(ra.cosT[cs]), sn = bf2f(ra.sinT[cs]);
+            const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
+            const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
+            bf16_t* dst = head < ra.Hq ? ra.qout + ((size_t)m * ra.Hq + head) * ra.D
+                                       : ra.kc + (((size_t)m * ra.Hkv + (head - ra.Hq)) * ra.Tmax + ra.slot) * ra.D;
+            dst[j] = f2bf(o0);
+            dst[j + half] = f2bf(o1);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = rb0[0] + fg * 4 + r;
+            if (n >= N) continue;
+            float v = acc[0][r] + (bias ? bf2f(bias[n]) : 0.f);
+            if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
+            if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+            out[(size_t)m * ldo + n] = f2bf(v);
+        }
+    }
+}
+
 struct GemvArgs {
     const bf16_t *X, *W, *bias, *res, *norm_w;
     bf16_t* out;
@@ -443,6 +645,7 @@ struct GemvArgs {
     int N, K, ldx, ldw, ldo, ldr, epi;
     hipStream_t s;
     RopeArgs ra;
+    bool packed;  // W points at the MFMA-fragment-major image (M >= 2 path only)
 };
 
 template <int M, int R, int KS, bool NORM>
@@ -530,16 +733,82 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     return O3V_OK;
 }
 
+template <int EPI, bool NORM, int KS, bool PACKED>
+static int launch_gemv_mfma_p(const GemvArgs& a, int M);
+
+template <int EPI, bool NORM, int KS>
+static int launch_gemv_mfma_t(const GemvArgs& a, int M) {
+    if (a.packed) return launch_gemv_mfma_p<EPI, NORM, KS, true>(a, M);
+    return launch_gemv_mfma_p<EPI, NORM, KS, false>(a, M);
+}
+
+template <int EPI, bool NORM, int KS, bool PACKED>
+static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
+    constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
+    const int groups = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? a.N / 32 : (a.N + 15) / 16;
+    constexpr int RG = 4 / KS;
+    dim3 grid((groups + RG - 1) / RG), block(256);
+    const size_t shmem = (NORM ? (size_t)M * (a.K * 2 + 16) : 0) + (KS > 1 ? (size_t)4 * RB * 64 * 16 : 0) + (NORM ? 16 * 4 * 4 : 0);
+    O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, a.eps, M,
+                a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+    return O3V_OK;
+}
+
+static int launch_gemv_mfma(const GemvArgs& a, int M) {
+    const int groups = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 32 : (a.N + 15) / 16;
+    // wave tasks = row groups x K slices: aim at >= 2048 waves (8 per CU) so enough weight loads are in flight
+    const int ks = groups >= 2048 ? 1 : (groups >= 1024 ? 2 : 4);
+#define O3V_MK(E, NRM)                                                       \
+    do {                                                                     \
+        if (ks == 1) return launch_gemv_mfma_t<E, NRM, 1>(a, M);             \
+        if (ks == 2) return launch_gemv_mfma_t<E, NRM, 2>(a, M);             \
+        return launch_gemv_mfma_t<E, NRM, 4>(a, M);                          \
+    } while (0)
+#define O3V_MM(E)                     \
+    do {                              \
+        if (a.norm_w) O3V_MK(E, true); \
+        O3V_MK(E, false);             \
+    } while (0)
+    switch (a.epi) {
+        case EPI_NONE: O3V_MM(EPI_NONE);
+        case EPI_RESIDUAL: O3V_MM(EPI_RESIDUAL);
+        case EPI_GELU: O3V_MM(EPI_GELU);
+        case EPI_SWIGLU: O3V_MM(EPI_SWIGLU);
+        case EPI_QKVROPE:
+            if (!a.norm_w) return O3V_ERR_ARG;
+            O3V_MK(EPI_QKVROPE, true);
+        default: return O3V_ERR_ARG;
+    }
+#undef O3V_MM
+#undef O3V_MK
+}
+
 static int gemv_dispatch(const void* X, const void* W, const void* bias, const void* res, void* out, const void* norm_w,
                          float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
-                         hipStream_t stream, const RopeArgs* ra = nullptr) {
+                         hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr) {
     if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 8) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
     GemvArgs a{(const bf16_t*)X, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w,
-               (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream, ra ? *ra : RopeArgs{}};
+               (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream, ra ? *ra : RopeArgs{}, false};
+    // with the fragment-major weight image every wave-instruction of the matrix-core path reads one contiguous KiB;
+    // on row-major weights its 64-byte row segments cost ~25 % of the bandwidth
+    // (M = 2, 3: the scalar dot2 GEMV still streams at ~5.8 TB/s, measured in profiles/r01_m8_linear.txt)
+    if (Wp && M >= 4) {
+        a.W = (const bf16_t*)Wp;
+        a.packed = true;
+    }
+    if (M >= 4 && (K % 32) == 0 && (N % 16) == 0 && (epilogue != EPI_QKVROPE || (a.ra.D % 32) == 0) &&
+        (epilogue != EPI_SWIGLU || (N % 32) == 0) && (!a.packed || (N % 16 == 0)) && (!norm_w || (size_t)M * (K * 2 + 16) <= 120 * 1024)) {
+        int rcm = launch_gemv_mfma(a, M);
+        if (rcm != O3V_OK) return rcm;
+        O3V_CHECK_LAUNCH();
+        return O3V_OK;
+    }
+    a.W = (const bf16_t*)W;  // scalar path reads the row-major image
+    a.packed = false;
     int rc;
 #define O3V_M(MM) rc = norm_w ? launch_gemv_m<MM, true>(a) : launch_gemv_m<MM, false>(a)
     switch (M) {
@@ -575,17 +844,26 @@ extern "C" int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, 
     return gemv_dispatch(X, W, bias, res, out, norm_w, eps, M, N, K, ldx, ldw, ldo, ldr, epilogue, stream);
 }
 
+// Decode linear with both weight images: `W` row-major [N,K] (M = 1: scalar GEMV at the HBM copy rate) and `Wp` its
+// MFMA-fragment-major copy [N/16][K/32][64][8] (2 <= M <= 8: matrix-core skinny GEMM streaming 1 KiB per
+// wave-instruction).  norm_w may be NULL (no fused RMSNorm); Wp may be NULL (row-major only).
+extern "C" int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* W, const void* Wp,
+                                 const void* bias, const void* res, void* out, int M, int N, int K, int ldx, int ldo,
+                                 int ldr, int epilogue, hipStream_t stream) {
+    return gemv_dispatch(X, W, bias, res, out, norm_w, eps, M, N, K, ldx, K, ldo, ldr, epilogue, stream, nullptr, Wp);
+}
+
 // Decode q/k/v projection with everything around it fused: RMSNorm prologue, bias, M-RoPE, q written to qout[M,Hq,D],
 // k and v appended to the cache at `slot` (TF:733-736 norm, :636-664 projection + rope + cache update).
-extern "C" int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* bias, int M,
-                                      int K, int ldx, const void* cosT, const void* sinT, void* qout, void* kcache,
-                                      void* vcache, int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off,
-                                      hipStream_t stream) {
+extern "C" int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* Wp,
+                                      const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT,
+                                      void* qout, void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax,
+                                      int cs_stride_row, int cs_off, hipStream_t stream) {
     if (!norm_w || !cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 ||
         (D & 1))
         return O3V_ERR_ARG;
     RopeArgs ra{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache,
                 slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
     return gemv_dispatch(X, W, bias, nullptr, nullptr, norm_w, eps, M, (Hq + 2 * Hkv) * D, K, ldx, K, 0, 0, EPI_QKVROPE, stream,
-                         &ra);
+                         &ra, Wp);
 }

@@ -3,7 +3,7 @@
 // :527-539 (top-p: drop the ascending-sorted prefix whose cumulative probability is <= 1-top_p, keep >= 1)
 // and TF:generation/utils.py:2921-2923 (softmax -> multinomial) as used by the GSPO rollout
 // (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313: do_sample, top_p 0.95, temperature 1).
-// The top-p cut is found by bisection on the probability value (the kept set is {p >= tau}); the draw walks the
+// The top-p cut is found by a radix select on the probability bit pattern (kept set {p >= tau}); the draw walks the
 // kept mass in index order.  RNG: counter-based (splitmix64 of seed, completion id, step) so a completion is
 // reproducible wherever it is generated.
 #include "o3v_common.h"
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const bf16_t* __rest
                                                             int out_stride, float* __restrict__ scratch) {
     __shared__ float red[16];
     __shared__ float csum[1024];
+    __shared__ float hist[4096];
     __shared__ int s_pick;
+    __shared__ float s_below;
     const int b = blockIdx.x, tid = threadIdx.x;
     const bf16_t* lr = logits + (size_t)b * ldl;
     uint8_t* sr = seen + (size_t)b * V;
@@ -70,20 +72,81 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const bf16_t* __rest
     }
     z = block_sum(z, red);
     const float invz = 1.0f / z;
-    // 3. top-p threshold by bisection on p: M(t) = sum_{p<=t} p ; keep p > lo where M(lo) <= 1-top_p < M(hi)
-    float lo = 0.f, hi = invz;  // the max probability is exp(0)/z
+    // 3. top-p threshold by a 3-level radix select on the bit pattern of p (positive floats order like their bits):
+    //    smallest tau with M(tau) = sum_{p <= tau} p > 1 - top_p; the kept set is {p >= tau} (TF keeps the complement of
+    //    the ascending prefix with cumulative probability <= 1 - top_p).  Each level histograms probability MASS over
+    //    12 / 12 / 7 bits of the elements that match the prefix found so far: 3 passes instead of a 30-pass bisection.
+    float lo = 0.f;  // kept: p > lo  (lo = largest representable value below tau)
     if (top_p < 1.0f) {
         const float cut = 1.0f - top_p;
-        for (int it = 0; it < 30; ++it) {
-            const float mid = 0.5f * (lo + hi);
-            float mass = 0.f;
+        unsigned prefix = 0;       // bits of tau decided so far (high bits)
+        float below = 0.f;         // mass of all p whose high bits are < prefix
+        const int shifts[3] = {19, 7, 0};
+        const int widths[3] = {12, 12, 7};
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            const int sh = shifts[lvl], nb = 1 << widths[lvl];
+            for (int i = tid; i < nb; i += 1024) hist[i] = 0.f;
+            __syncthreads();
+            const unsigned hi_mask = (lvl == 0) ? 0u : (0xffffffffu << (sh + widths[lvl]));
             for (int i = tid; i < V; i += 1024) {
                 const float p = pr[i] * invz;
-                mass += (p <= mid) ? p : 0.f;
+                const unsigned bits = __float_as_uint(p);
+                if ((bits & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(bits >> sh) & (nb - 1)], p);
             }
-            mass = block_sum(mass, red);
-            if (mass <= cut) lo = mid; else hi = mid;
+            __syncthreads();
+            // exclusive scan of the bins in ascending order; every thread owns nb/1024 (>= 1) consecutive bins
+            const int per = nb >= 1024 ? nb / 1024 : 1;
+            float mine = 0.f;
+            if (tid * per < nb)
+                for (int k = 0; k < per; ++k) mine += hist[tid * per + k];
+            float incl = mine;  // inclusive scan across the block
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float t = __shfl_up(incl, o, 64);
+                if ((tid & 63) >= o) incl += t;
+            }
+            if ((tid & 63) == 63) red[tid >> 6] = incl;
+            __syncthreads();
+            float wave_off = 0.f;
+            for (int w = 0; w < (tid >> 6); ++w) wave_off += red[w];
+            const float before = below + wave_off + incl - mine;
+            if (tid == 0) s_pick = -1;
+            __syncthreads();
+            if (tid * per < nb && mine > 0.f && before <= cut && before + mine > cut) {
+                float run = before;
+                for (int k = 0; k < per; ++k) {
+                    const float h = hist[tid * per + k];
+                    if (h > 0.f && run + h > cut) {
+                        s_pick = tid * per + k;
+                        s_below = run;
+                        break;
+                    }
+                    run += h;
+                }
+            }
+            __syncthreads();
+            if (s_pick < 0) {  // rounding left the crossing undetected: take the highest non-empty bin
+                if (tid == 0) {
+                    float run = below;
+                    int lastb = 0;
+                    float lastrun = below;
+                    for (int k = 0; k < nb; ++k)
+                        if (hist[k] > 0.f) {
+                            lastb = k;
+                            lastrun = run;
+                            run += hist[k];
+                        }
+                    s_pick = lastb;
+                    s_below = lastrun;
+                }
+                __syncthreads();
+            }
+            prefix |= ((unsigned)s_pick) << sh;
+            below = s_below;
+            __syncthreads();
         }
+        // tau = prefix (all 31 value bits decided); keep p >= tau  <=>  p > tau_minus
+        lo = __uint_as_float(prefix > 0 ? prefix - 1 : 0u);
     }
     // 4. kept mass per contiguous index chunk, then the draw
     const int chunk = (V + 1023) / 1024;

@@ -37,6 +37,15 @@ def pack_gate_up(gate: torch.Tensor, up: torch.Tensor, ipad: int) -> torch.Tenso
     return torch.stack([g, u], dim=1).reshape((2 * ipad,) + tail).contiguous()
 
 
+def pack_mfma_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] row-major -> MFMA-fragment-major [N/16][K/32][64 lanes][8]: lane l of the A fragment of (row block nb,
+    k-step ks) holds W[nb*16 + (l & 15)][ks*32 + (l >> 4)*8 : +8], so one wave-instruction reads one contiguous KiB
+    (csrc/o3v_gemm.hip gemv_mfma_kernel<PACKED>).  Requires N % 16 == 0 and K % 32 == 0."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
 def pad_cols(w: torch.Tensor, kpad: int) -> torch.Tensor:
     if w.shape[1] == kpad:
         return w.contiguous()
@@ -63,7 +72,9 @@ class _Getter:
 class DeviceWeights:
     """Owns the packed tensors and the ctypes descriptors that point at them."""
 
-    def __init__(self, cfg: O3VConfig, get: Callable[[str], torch.Tensor], device="cuda"):
+    def __init__(self, cfg: O3VConfig, get: Callable[[str], torch.Tensor], device="cuda", batched_decode: bool = True):
+        """batched_decode: also keep MFMA-fragment-major copies of the LLM matrices (+1x their size in HBM) so that
+        decoding 2..8 sequences together (group rollout) streams weights at the same rate as batch 1."""
         self.cfg = cfg
         self.device = torch.device(device)
         g = _Getter(get, self.device)
@@ -125,6 +136,11 @@ class DeviceWeights:
             keep[f"l{i}.down_w"] = pad_cols(l(b + "mlp.down_proj.weight"), tc.inter_pad)
             for f in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w"):
                 setattr(self.llm_layers[i], f, keep[f"l{i}.{f}"].data_ptr())
+            for f in ("qkv_w", "o_w", "gu_w", "down_w"):
+                w = keep[f"l{i}.{f}"]
+                if batched_decode and w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
+                    keep[f"l{i}.{f}p"] = pack_mfma_fragments(w)
+                    setattr(self.llm_layers[i], f + "p", keep[f"l{i}.{f}p"].data_ptr())
         keep["l.norm"] = l("norm.weight").contiguous()
         if tc.tie_word_embeddings:
             keep["l.head"] = keep["l.embed"]
@@ -133,11 +149,15 @@ class DeviceWeights:
                 keep["l.head"] = g("lm_head.weight").contiguous()
             except KeyError:
                 keep["l.head"] = keep["l.embed"]
+        head_p = 0
+        if batched_decode and keep["l.head"].shape[0] % 16 == 0 and keep["l.head"].shape[1] % 32 == 0:
+            keep["l.headp"] = pack_mfma_fragments(keep["l.head"])
+            head_p = keep["l.headp"].data_ptr()
         self.llm = _lib.LlmDesc(hidden=tc.hidden_size, layers=tc.num_hidden_layers, heads=tc.num_attention_heads,
                                 kv_heads=tc.num_key_value_heads, head_dim=tc.head_dim, inter=tc.inter_pad,
                                 vocab=tc.vocab_size, rms_eps=tc.rms_norm_eps, embed=keep["l.embed"].data_ptr(),
                                 layer=self.llm_layers, final_norm=keep["l.norm"].data_ptr(),
-                                lm_head=keep["l.head"].data_ptr())
+                                lm_head=keep["l.head"].data_ptr(), lm_head_p=head_p)
         self._check_shapes()
 
     def _check_shapes(self):

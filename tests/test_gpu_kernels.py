@@ -180,13 +180,60 @@ def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
     _lib.call("o3v_qkv_rope_cache", P(qkv), P(cos), P(sin), P(q1), P(k1), P(v1), slot, M, 1, Hq, Hkv, D, Tmax, Tnew, step, st)
     # fused
     q2, k2, v2 = torch.zeros_like(q1), torch.zeros_like(k1), torch.zeros_like(v1)
-    _lib.call("o3v_gemv_norm_qkv_rope", P(x), P(nw), 1e-6, P(w), P(bias), M, K, K, P(cos), P(sin), P(q2), P(k2), P(v2), slot,
-              Hq, Hkv, D, Tmax, Tnew, step, st)
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    _lib.call("o3v_gemv_norm_qkv_rope", P(x), P(nw), 1e-6, P(w), None, P(bias), M, K, K, P(cos), P(sin), P(q2), P(k2), P(v2),
+              slot, Hq, Hkv, D, Tmax, Tnew, step, st)
+    # same with the fragment-major weight image (matrix-core path from M = 2)
+    wp = pack_mfma_fragments(w)
+    q3, k3, v3 = torch.zeros_like(q1), torch.zeros_like(k1), torch.zeros_like(v1)
+    _lib.call("o3v_gemv_norm_qkv_rope", P(x), P(nw), 1e-6, P(w), P(wp), P(bias), M, K, K, P(cos), P(sin), P(q3), P(k3), P(v3),
+              slot, Hq, Hkv, D, Tmax, Tnew, step, st)
+    close_bf16(q3, q1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(k3, k1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(v3, v1.float(), ulps=1, atol=2e-3, frac=0.999)
     # the fused kernel splits K over 2 waves, the unfused gemv may not: allow 1 bf16 ulp on the projection
     close_bf16(q2, q1.float(), ulps=1, atol=2e-3, frac=0.999)
     close_bf16(k2, k1.float(), ulps=1, atol=2e-3, frac=0.999)
     close_bf16(v2, v1.float(), ulps=1, atol=2e-3, frac=0.999)
     assert (k2[:, :, :slot] == 0).all() and (k2[:, :, slot + 1:] == 0).all()
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("N,K,epi_name,norm", [(4608, 3584, "none", True), (37888, 3584, "swiglu", True), (3584, 18944, "res", False),
+                                               (3584, 3584, "res", False), (152064, 3584, "none", True), (512, 128, "gelu", False),
+                                               (2304, 896, "swiglu", True)])
+def test_linear_decode_packed_weights(dev, M, N, K, epi_name, norm):
+    """o3v_linear_decode with the MFMA-fragment-major weight copy == the row-major path (all epilogues, fused norm)."""
+    import ctypes as C
+    from open_o3_video_amd import ops, _lib
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wp = pack_mfma_fragments(w)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    epi = {"none": ops.EPI_NONE, "swiglu": ops.EPI_SWIGLU, "res": ops.EPI_RESIDUAL, "gelu": ops.EPI_GELU}[epi_name]
+    No = N // 2 if epi == ops.EPI_SWIGLU else N
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for use_p in (False, True):
+        out = torch.empty(M, No, dtype=BF, device=dev)
+        _lib.call("o3v_linear_decode", P(x), P(nw) if norm else None, 1e-6, P(w), P(wp) if use_p else None, P(bias),
+                  P(res) if epi == ops.EPI_RESIDUAL else None, P(out), M, N, K, K, No, N, epi, st)
+        outs.append(out)
+    # reference: fp32 matmul with the same rounding points
+    from oracle import model_ref
+    xn = model_ref.rmsnorm(x.cpu(), nw.cpu(), 1e-6).to(dev) if norm else x
+    if epi == ops.EPI_SWIGLU:
+        ref = ops.gemm(xn, w, bias, None, epi, force="gemv" if M <= 8 else "gemm")
+        close_bf16(outs[1], ref.float(), ulps=1, atol=1e-3, frac=0.999)
+    else:
+        acc = xn.float() @ w.float().t()
+        close_bf16(outs[1], _epi_ref(acc, bias, res if epi == ops.EPI_RESIDUAL else None, epi))
+    close_bf16(outs[1], outs[0].float(), ulps=1, atol=1e-3, frac=0.999)
 
 
 def test_gemm_rejects_bad_shapes(dev):

@@ -18,7 +18,7 @@ from open_o3_video_amd.weights import DeviceWeights, random_getter  # noqa: E402
 cfg = O3VConfig.from_dict(qwen25vl_7b_dict())
 dev = torch.device("cuda")
 eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
-which = sys.argv[1:] or ["eval", "rollout", "long"]
+which = [a for a in sys.argv[1:] if not a.startswith("G")] or ["eval", "rollout", "long"]
 
 
 def run(tag, frames_n, H, W, S_target, T, **kw):
@@ -41,7 +41,7 @@ def run(tag, frames_n, H, W, S_target, T, **kw):
 if "eval" in which:
     run("EVAL-RES 32x364x644 greedy B=1", 32, 364, 644, 10218, 256, repetition_penalty=1.05)
 if "rollout" in which:
-    for G in (2, 4, 8):
+    for G in ([int(a[1:]) for a in sys.argv[1:] if a.startswith('G')] or (2, 4, 8)):
         run(f"rollout G={G} sampled top_p=0.95 (TRAIN-RES)", 32, 224, 420, 4490, 256, num_return_sequences=G, do_sample=True,
             top_p=0.95, temperature=1.0, seed=1)
 if "long" in which:
