@@ -109,6 +109,93 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     }
 
     // ---- epilogue.  C/D map of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
+    // Fast path: the wave's 64x64 fp32 sub-tile goes through LDS (row stride 68 floats: the two 32-lane halves of a
+    // ds_write_b32 land on disjoint banks) and comes back row-wise, 8 consecutive columns per lane, so bias / residual are
+    // 16-byte loads and every output row segment is a 16-byte store of a full 128-byte line per 8 lanes.
+    const bool vec_ok = ((N & 7) == 0) && ((ldo & 7) == 0) && (EPI != EPI_RESIDUAL || (ldr & 7) == 0);
+    if (vec_ok) {
+        constexpr int ES = 68;
+        float* et = reinterpret_cast<float*>(smem) + wave * 64 * ES;  // main loop ended with a barrier: tiles are dead
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) et[(i * 16 + fg * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
+        // same wave writes and reads its own region; LDS operations of a wave complete in order
+        const int mrow0 = m0 + wm * 64;
+        if (EPI == EPI_SWIGLU) {
+            const int no0 = (n0 + wn * 64) >> 1;  // first output column of this wave (32 per wave)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + (lane >> 2), oc = (lane & 3) * 8;
+                const int m = mrow0 + row, no = no0 + oc;
+                if (m >= M || no >= (N >> 1)) continue;
+                const int gcol = (oc >> 4) * 32 + (oc & 15);  // gate columns in the tile; up = +16
+                const float* gp = et + row * ES + gcol;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(gp + 16), u1 = *reinterpret_cast<const f32x4*>(gp + 20);
+                float gb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (bias) {
+                    const int ng = n0 + wn * 64 + gcol;
+                    const u32x4 bg = *reinterpret_cast<const u32x4*>(bias + ng), bu = *reinterpret_cast<const u32x4*>(bias + ng + 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gb[2 * q] = bf_lo(bg[q]);
+                        gb[2 * q + 1] = bf_hi(bg[q]);
+                        ub[2 * q] = bf_lo(bu[q]);
+                        ub[2 * q + 1] = bf_hi(bu[q]);
+                    }
+                }
+                float o8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float gv = rbf((q < 4 ? g0[q] : g1[q - 4]) + gb[q]);
+                    const float uv = rbf((q < 4 ? u0[q] : u1[q - 4]) + ub[q]);
+                    o8[q] = rbf(silu_f(gv)) * uv;
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(o8[2 * q], o8[2 * q + 1]);
+                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + no) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                const int m = mrow0 + row, n = n0 + wn * 64 + c8;
+                if (m >= M || n >= N) continue;
+                const float* ep = et + row * ES + c8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep), v1 = *reinterpret_cast<const f32x4*>(ep + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (bias) {
+                    const u32x4 bb = *reinterpret_cast<const u32x4*>(bias + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] += bf_lo(bb[q]);
+                        v[2 * q + 1] += bf_hi(bb[q]);
+                    }
+                }
+                if (EPI == EPI_RESIDUAL) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldr + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = rbf(v[2 * q]) + bf_lo(rr[q]);
+                        v[2 * q + 1] = rbf(v[2 * q + 1]) + bf_hi(rr[q]);
+                    }
+                }
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf_f(rbf(v[q]));
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
+                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = pk;
+            }
+        }
+        return;
+    }
     if (EPI == EPI_SWIGLU) {
         // W rows interleaved in 16-row groups: even groups = gate rows, odd groups = up rows of the same
         // 16 output columns (host packs them), so acc[i][2jj] / acc[i][2jj+1] meet in one lane.
@@ -717,7 +804,7 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     if (M == 0) return O3V_OK;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-    const size_t shmem = 4 * TILE_BYTES;
+    const size_t shmem = 4 * 64 * 68 * 4;  // max(2 stages x (A+B) = 64 KiB, epilogue staging 4 waves x 64 x 68 f32)
 #define O3V_GM(E)                                                                                                       \
     O3V_KLAUNCH((gemm_bf16_kernel<E>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)W,            \
                        (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, lda, ldw, ldo, ldr, tiles_m, tiles_n)

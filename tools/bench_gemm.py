@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Throughput of o3v_gemm_bf16 on the prefill / ViT shapes of the 7B benchmark (random operands, L2-cold rotation)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_o3_video_amd import _lib  # noqa: E402
+
+dev = torch.device("cuda")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+shapes = [  # name, M, N(weight rows), K, epi, bias
+    ("llm qkv", 4490, 4608, 3584, 0, True), ("llm o+res", 4490, 3584, 3584, 1, False),
+    ("llm gate/up swiglu", 4490, 37888, 3584, 3, False), ("llm down+res", 4490, 3584, 18944, 1, False),
+    ("vit qkv", 15360, 3840, 1280, 0, True), ("vit proj+res", 15360, 1280, 1280, 1, True),
+    ("vit gate/up swiglu", 15360, 6912, 1280, 3, True), ("vit down+res", 15360, 1280, 3456, 1, True),
+    ("square 4096", 4096, 4096, 4096, 0, False), ("square 8192", 8192, 8192, 8192, 0, False),
+]
+g = torch.Generator(device=dev).manual_seed(0)
+tot_t, tot_f = 0.0, 0.0
+for name, M, N, K, epi, hb in shapes:
+    nrep = 3
+    a = [torch.empty(M, K, dtype=torch.bfloat16, device=dev).uniform_(-1, 1, generator=g) for _ in range(nrep)]
+    w = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).uniform_(-1, 1, generator=g) for _ in range(nrep)]
+    bias = torch.zeros(N, dtype=torch.bfloat16, device=dev) if hb else None
+    No = N // 2 if epi == 3 else N
+    res = torch.zeros(M, No, dtype=torch.bfloat16, device=dev) if epi == 1 else None
+    out = torch.empty(M, No, dtype=torch.bfloat16, device=dev)
+
+    def run():
+        for i in range(nrep):
+            _lib.call("o3v_gemm_bf16", P(a[i]), P(w[i]), P(bias), P(res), P(out), M, N, K, K, K, No, No, epi, st)
+    run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / nrep)
+    t = sorted(ts)[2]
+    fl = 2.0 * M * N * K
+    print(f"{name:22s} M={M:6d} N={N:6d} K={K:6d}  {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s", flush=True)
+    del a, w
