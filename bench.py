@@ -177,12 +177,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal knobs (one-GPU box): O3V_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, O3V_DIST_BACKEND=gloo swaps RCCL out
+    if os.environ.get("O3V_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("O3V_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        if backend == "nccl":
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        else:
+            dist_.init_process_group(backend)
         dist = dist_
 
     from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict, qwen25vl_7b_dict
@@ -192,7 +199,7 @@ def main():
     cfg_dict = qwen25vl_7b_dict() if args.model == "7b" else qwen25vl_3b_dict()
     cfg = O3VConfig.from_dict(cfg_dict)
     dev = torch.device("cuda", local_rank)
-    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=False))  # B=1: row-major only
     Hres, Wres = (224, 420) if args.res == "train" else (364, 644)
     tpf = (Hres // 28) * (Wres // 28)
     S = 4490 if args.res == "train" else 10218
@@ -223,7 +230,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.sequences.shape[1] == S + args.new_tokens

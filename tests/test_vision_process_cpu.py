@@ -1,0 +1,90 @@
+"""CPU tests of the data facade (open_o3_video_amd/vision_process.py) against the reference-generated policy goldens
+and the reference's documented behaviour (R:src/r1-v/src/open_r1/vision_process.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from open_o3_video_amd import vision_process as vp
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    with open(os.path.join(golden_dir, "g1_policy.json")) as f:
+        return json.load(f)
+
+
+def test_policy_functions_match_reference(g1):
+    for k, v in g1["constants"].items():
+        assert getattr(vp, k) == v, k
+    for h, w, f, mn, mx, exp in g1["smart_resize"]:
+        if exp == "ValueError":
+            with pytest.raises(ValueError):
+                vp.smart_resize(h, w, f, mn, mx)
+        else:
+            assert list(vp.smart_resize(h, w, f, mn, mx)) == exp
+    for n, f, r, c, fl in g1["by_factor"]:
+        assert (vp.round_by_factor(n, f), vp.ceil_by_factor(n, f), vp.floor_by_factor(n, f)) == (r, c, fl)
+    for ele, total, vfps, exp in g1["smart_nframes"]:
+        if isinstance(exp, str):
+            with pytest.raises((ValueError, AssertionError)):
+                vp.smart_nframes(dict(ele), total, vfps)
+        else:
+            assert vp.smart_nframes(dict(ele), total, vfps) == exp
+    for total, n, idx in g1["linspace"]:
+        assert vp.sample_indices(total, n).tolist() == idx
+    for n, h, w, ele, exp in g1["video_hw"]:
+        mn, mx = vp.video_pixel_budget(n, ele)
+        assert list(vp.smart_resize(h, w, 28, mn, mx)) == exp
+    ev = g1["extract_vision_info"]
+    assert vp.extract_vision_info(ev["conv"]) == ev["single"]
+    assert vp.extract_vision_info([ev["conv"], ev["conv"]]) == ev["nested"]
+
+
+def test_frame_prompts_match_reference(g1):
+    for c in g1["frame_prompts"]:
+        p = "sys " + vp.VIDEO_TAG + " question"
+        assert vp.frames_as_images_prompt(p, c["n"], c["fps"], "trainer") == "sys " + c["trainer"] + " question"
+        assert vp.frames_as_images_prompt(p, c["n"], c["fps"], "demo") == "sys " + c["demo"] + " question"
+        assert vp.frames_as_images_prompt(p, 0, 0, "vstar", c["vstar_times"]) == "sys " + c["vstar"] + " question"
+        assert vp.frames_as_images_prompt("no tag", 0, 0, "vstar", c["vstar_times"]) == c["vstar"] + "no tag"
+
+
+def test_process_vision_info_video_tensor_and_images():
+    # pre-decoded 640x360 clip, 491 frames @22.29 fps, nframes 32 -> the SURVEY's canonical TRAIN-RES 224x420
+    g = torch.Generator().manual_seed(0)
+    clip = torch.randint(0, 256, (491, 3, 36, 64), generator=g, dtype=torch.uint8)  # small spatial size for speed
+    clip = torch.nn.functional.interpolate(clip.float(), size=(360, 640)).to(torch.uint8)
+    conv = [{"role": "system", "content": "s"},
+            {"role": "user", "content": [{"type": "video", "video": clip, "nframes": 32, "video_fps": 22.29},
+                                         {"type": "text", "text": "q"}]}]
+    imgs, vids, kw = vp.process_vision_info(conv, return_video_kwargs=True)
+    assert imgs is None and len(vids) == 1
+    assert vids[0].shape == (32, 3, 224, 420) and vids[0].dtype == torch.float32
+    assert 0 <= vids[0].min() and vids[0].max() <= 255
+    assert kw["fps"][0] == pytest.approx(32 / 491 * 22.29)
+    two = vp.process_vision_info(conv)
+    assert len(two) == 2
+    # images: RGBA -> white background, smart_resize to multiples of 28
+    rgba = Image.new("RGBA", (100, 60), (255, 0, 0, 0))
+    out, vids2 = vp.process_vision_info([{"role": "user", "content": [{"type": "image", "image": rgba}, {"type": "text", "text": "x"}]}])
+    assert vids2 is None and out[0].mode == "RGB" and out[0].size == (112, 56)
+    assert out[0].getpixel((5, 5)) == (255, 255, 255)
+    # list-of-frames video: padded to an even count (R:vision_process.py:319-333)
+    frames = [Image.new("RGB", (64, 36), (i, i, i)) for i in range(3)]
+    v, fps = vp.fetch_video({"video": frames, "fps": 1.5}, return_video_sample_fps=True)
+    assert len(v) == 4 and fps == 1.5 and v[3].getpixel((0, 0)) == v[2].getpixel((0, 0))
+    with pytest.raises(ValueError):
+        vp.process_vision_info([{"role": "user", "content": [{"type": "video"}]}])
+
+
+def test_resized_height_width_and_budget():
+    clip = torch.zeros(8, 3, 100, 200, dtype=torch.uint8)
+    v = vp.fetch_video({"video": clip, "resized_height": 120, "resized_width": 250})
+    assert v.shape[-2:] == (112, 252)
+    mn, mx = vp.video_pixel_budget(768, {})
+    assert mn == 128 * 784 and mx == int(mn * 1.05)   # many frames: floor at 1.05 * min_pixels (R:...:291)
+    assert vp.video_pixel_budget(32, {"max_pixels": 50176})[1] == 50176

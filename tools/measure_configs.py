@@ -46,3 +46,10 @@ if "rollout" in which:
             top_p=0.95, temperature=1.0, seed=1)
 if "long" in which:
     run("LONG 256x224x224 greedy B=1", 256, 224, 224, 256 * (64 + 15) + 170, 128, repetition_penalty=1.05)
+
+if "3b" in which:
+    # BASELINE config #1 shapes: Qwen2.5-VL-3B dims (tied embeddings, GQA 8:1), 4 frames at EVAL-RES, 256 new tokens
+    from open_o3_video_amd.config import qwen25vl_3b_dict
+    cfg = O3VConfig.from_dict(qwen25vl_3b_dict())
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
+    run("config#1 3B dims, 4x364x644 greedy", 4, 364, 644, 4 * (299 + 15) + 170, 256, repetition_penalty=1.05)
