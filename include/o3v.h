@@ -92,11 +92,12 @@ int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* 
                       o3v_stream_t stream);
 
 /* ---- attention ---------------------------------------------------------------------------------------------- */
-/* tiles: int32[n_tiles][8] = {q_row0, q_rows, k_row0, k_len, causal_off, k_lo, batch, 0}.
+/* tiles: int32[n_tiles][8] = {q_row0, q_rows (<= rows_per_tile), k_row0, k_len, causal_off, k_lo, batch, 0};
+ * rows_per_tile 64 (ragged ViT windows) or 128 (prefill).
  * ViT varlen attention (TF:248-287) and causal GQA prefill attention (TF:186-208, :602-689). */
-int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int Hq, int n_rep,
-                   int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
-                   float scale, o3v_stream_t stream);
+int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int rows_per_tile,
+                   int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs, long v_bs,
+                   long o_ts, float scale, o3v_stream_t stream);
 /* q_len == 1 attention against the cache [B,Hkv,Tmax,D]; part_o: f32[B*Hq*nsplit*D], part_ml: f32[B*Hq*nsplit*2] */
 int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                     const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
@@ -166,8 +167,8 @@ size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 /* Qwen2_5_VLTextModel.forward over the prompt, TF:790-872: x bf16 [B*S,H] holds inputs_embeds on entry and the
  * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D]. */
 int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
-                    void* kcache, void* vcache, int B, int S, int Tmax, void* workspace, size_t ws_bytes,
-                    o3v_stream_t stream);
+                    int rows_per_tile, void* kcache, void* vcache, int B, int S, int Tmax, void* workspace,
+                    size_t ws_bytes, o3v_stream_t stream);
 /* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
 int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                  o3v_stream_t stream);

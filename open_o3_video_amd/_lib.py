@@ -61,7 +61,7 @@ SIGNATURES = {
     "o3v_prefetch": [vp, sz, i32, vp, vp],
     "o3v_gemm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
+    "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
     "o3v_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -73,7 +73,7 @@ SIGNATURES = {
     "o3v_vit_workspace_bytes": [C.POINTER(VitDesc), i32],
     "o3v_vit_forward": [C.POINTER(VitDesc), vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, sz, vp, vp],
     "o3v_llm_workspace_bytes": [C.POINTER(LlmDesc), i32],
-    "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, sz, vp],
+    "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, sz, vp],
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }

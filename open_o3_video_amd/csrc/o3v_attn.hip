@@ -44,7 +44,10 @@ struct AttnCfg {
     static constexpr int V_BYTES = 64 * VSTRIDE;
 };
 
-template <int D>
+// RQ = 16-row query blocks per wave (1: 64-row tiles for the ragged ViT windows; 2: 128-row tiles for the LLM prefill,
+// where every K fragment read and every transposed V read from LDS feeds two MFMAs instead of one -- the kernel is
+// LDS-bandwidth-bound at RQ = 1).
+template <int D, int RQ>
 __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          const TileDesc* __restrict__ tiles, long q_ts, long k_ts,
@@ -60,23 +63,32 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][ks*32 + 8*fg .. +7]
-    const int qrow_in = wave * 16 + fr;
-    const int qrow_ld = td.q_row0 + (qrow_in < td.q_rows ? qrow_in : td.q_rows - 1);
-    bf16x8 qf[C::KS];
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][ks*32 + 8*fg .. +7] of each of its RQ row blocks
+    int qrow_in[RQ];
+    bf16x8 qf[RQ][C::KS];
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-        const int d0 = ks * 32 + fg * 8;
-        if (d0 < D)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qrow_ld * q_ts + (size_t)h * D + d0);
-        else
-            qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int rq = 0; rq < RQ; ++rq) {
+        qrow_in[rq] = (wave * RQ + rq) * 16 + fr;
+        const int qrow_ld = td.q_row0 + (qrow_in[rq] < td.q_rows ? qrow_in[rq] : td.q_rows - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 32 + fg * 8;
+            if (d0 < D)
+                qf[rq][ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qrow_ld * q_ts + (size_t)h * D + d0);
+            else
+                qf[rq][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
     }
 
-    float m_run = -1e30f, l_run = 0.f;
-    f32x4 o[C::DB];
+    float m_run[RQ], l_run[RQ];
+    f32x4 o[RQ][C::DB];
 #pragma unroll
-    for (int i = 0; i < C::DB; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rq = 0; rq < RQ; ++rq) {
+        m_run[rq] = -1e30f;
+        l_run[rq] = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::DB; ++i) o[rq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const bf16_t* Kb = K + (size_t)td.batch * k_bs + (size_t)hk * k_hs + (size_t)td.k_row0 * k_ts;
     const bf16_t* Vb = V + (size_t)td.batch * v_bs + (size_t)hk * v_hs + (size_t)td.k_row0 * v_ts;
@@ -89,11 +101,52 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
     const int kt_lo = td.k_lo >> 6;
     const int kt_hi = (k_end + 63) >> 6;
 
+    // K/V staging.  A split form (global loads of tile kt+1 issued right after the barrier that publishes tile kt, written
+    // to LDS after the next barrier) is kept behind SPLIT: it costs 32 VGPRs and with them a block of occupancy, which
+    // measured slower than the plain load-store staging whose latency the co-resident blocks hide.
+    constexpr int CPR = C::DPAD / 8, VPR = D / 8;
+    constexpr int NKC = (64 * CPR + 255) / 256, NVC = (64 * VPR + 255) / 256;
+    constexpr bool SPLIT = false;  // measured on MI355X: the 32 extra VGPRs drop RQ = 2 to one block per CU: S=20k prefill 550 -> 700 ms
+    uint4 kreg[SPLIT ? NKC : 1], vreg[SPLIT ? NVC : 1];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            const int row = c / CPR, ch = c % CPR;
+            int kr = kt * 64 + row;
+            kr = kr < td.k_len ? kr : td.k_len - 1;
+            kreg[SPLIT ? i : 0] = make_uint4(0, 0, 0, 0);
+            if (c < 64 * CPR && ch * 8 < D) kreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(Kb + (size_t)kr * k_ts + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            const int row = c / VPR, ch = c % VPR;
+            int kr = kt * 64 + row;
+            kr = kr < td.k_len ? kr : td.k_len - 1;
+            if (c < 64 * VPR) vreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(Vb + (size_t)kr * v_ts + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < 64 * CPR) *reinterpret_cast<uint4*>(Kl + (c / CPR) * C::KSTRIDE + (c % CPR) * 16) = kreg[SPLIT ? i : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < 64 * VPR) *reinterpret_cast<uint4*>(Vl + (c / VPR) * C::VSTRIDE + (c % VPR) * 16) = vreg[SPLIT ? i : 0];
+        }
+    };
+    if (SPLIT && kt_lo < kt_hi) load_tile(kt_lo);
+
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         __syncthreads();  // previous tile fully consumed
-        // ---- stage K (zero padded to DPAD) and V tiles through registers
-        {
-            constexpr int CPR = C::DPAD / 8;
+        if (SPLIT) {
+            store_tile();
+        } else {
+            // ---- stage K (zero padded to DPAD) and V tiles through registers
             for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
                 const int row = c / CPR, ch = c % CPR;
                 int kr = kt * 64 + row;
@@ -102,7 +155,6 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
                 if (ch * 8 < D) v = *reinterpret_cast<const uint4*>(Kb + (size_t)kr * k_ts + ch * 8);
                 *reinterpret_cast<uint4*>(Kl + row * C::KSTRIDE + ch * 16) = v;
             }
-            constexpr int VPR = D / 8;
             for (int c = threadIdx.x; c < 64 * VPR; c += 256) {
                 const int row = c / VPR, ch = c % VPR;
                 int kr = kt * 64 + row;
@@ -112,52 +164,72 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
             }
         }
         __syncthreads();
+        if (SPLIT && kt + 1 < kt_hi) load_tile(kt + 1);
+        // wave-level skip: with a causal mask a wave whose rows all precede this key tile has nothing to do
+        if (td.causal_off >= 0 && kt * 64 > td.causal_off + (wave * RQ + RQ) * 16 - 1) continue;
 
-        // ---- S^T = K . Q^T : 4 key blocks of 16
-        f32x4 s[4];
+        // ---- S^T = K . Q^T : 4 key blocks of 16, every K fragment feeds RQ MFMAs
+        f32x4 s[RQ][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) s[rq][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const bf16x8 kf =
                     *reinterpret_cast<const bf16x8*>(Kl + (kb * 16 + fr) * C::KSTRIDE + (ks * 32 + fg * 8) * 2);
-                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) s[rq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][ks], s[rq][kb], 0, 0, 0);
             }
         }
-        // ---- mask, online softmax (query = fr, this lane's keys = kt*64 + kb*16 + 4*fg + r)
-        float mx = -1e30f;
-        bool ok[4][4];
+        // ---- online softmax on the raw scores (running max kept unscaled; p = exp2(s*c - m*c) is one fma + one exp2).
+        // Masking costs ~3x the arithmetic of the softmax itself, so it only runs on boundary tiles (left padding, the
+        // causal diagonal of this wave, the ragged tail); interior tiles take the mask-free path (wave-uniform branch).
+        bf16x8 pb[RQ][2];
+        const bool boundary = (kt * 64 < td.k_lo) || (kt * 64 + 63 >= td.k_len) ||
+                              (td.causal_off >= 0 && kt * 64 + 63 > td.causal_off + wave * RQ * 16);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int rq = 0; rq < RQ; ++rq) {
+            float mx = -1e30f;
+            if (boundary) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = kt * 64 + kb * 16 + fg * 4 + r;
-                bool v = (j < td.k_len) && (j >= td.k_lo);
-                if (td.causal_off >= 0) v = v && (j <= td.causal_off + qrow_in);
-                ok[kb][r] = v;
-                const float sv = v ? s[kb][r] * scale_log2e : -1e30f;
-                s[kb][r] = sv;
-                mx = fmaxf(mx, sv);
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = kt * 64 + kb * 16 + fg * 4 + r;
+                        bool v = (j < td.k_len) && (j >= td.k_lo);
+                        if (td.causal_off >= 0) v = v && (j <= td.causal_off + qrow_in[rq]);
+                        s[rq][kb][r] = v ? s[rq][kb][r] : -1e30f;
+                        mx = fmaxf(mx, s[rq][kb][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[rq][kb][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pb[2];
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[rq], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[rq] - m_new) * scale_log2e);
+            const float mc = -m_new * scale_log2e;
+            m_run[rq] = m_new;
+            float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = ok[kb][r] ? __builtin_amdgcn_exp2f(s[kb][r] - m_new) : 0.f;
-                psum += p;
-                pb[kb >> 1][(kb & 1) * 4 + r] = (short)f2bf(p);
-            }
-        l_run = l_run * alpha + psum;
+                for (int r = 0; r < 4; ++r) {
+                    // masked entries sit at -1e30: exp2 underflows to exactly 0 unless the whole row is still masked
+                    // (m_new = -1e30), where the explicit select keeps them out
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[rq][kb][r], scale_log2e, mc));
+                    if (boundary) p = (s[rq][kb][r] > -1e29f) ? p : 0.f;
+                    psum += p;
+                    pb[rq][kb >> 1][(kb & 1) * 4 + r] = (short)f2bf(p);
+                }
+            l_run[rq] = l_run[rq] * alpha + psum;
 #pragma unroll
-        for (int i = 0; i < C::DB; ++i) o[i] *= alpha;
+            for (int i = 0; i < C::DB; ++i) o[rq][i] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T.  k-slot j of lane group fg: j<4 -> key 32kk + 4fg + j ; j>=4 -> key 32kk + 16 + 4fg + (j-4)
         const int tq = fr >> 2, tp = fr & 3;  // tr-read: lane 4q+p of the 16-lane group addresses row q, cols 4p..4p+3
@@ -170,23 +242,27 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
                 const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + db * 32));
                 const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + db * 32));
                 const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[kk], o[db], 0, 0, 0);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) o[rq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[rq][kk], o[rq][db], 0, 0, 0);
             }
         }
     }
 
     // ---- finalize: l over the 4 lane groups, O[q][d = db*16 + 4fg + r]
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow_in < td.q_rows) {
-        bf16_t* orow = O + (size_t)(td.q_row0 + qrow_in) * o_ts + (size_t)h * D + fg * 4;
 #pragma unroll
-        for (int db = 0; db < C::DB; ++db) {
-            u32x2 pk;
-            pk[0] = pack_bf2(o[db][0] * inv, o[db][1] * inv);
-            pk[1] = pack_bf2(o[db][2] * inv, o[db][3] * inv);
-            *reinterpret_cast<u32x2*>(orow + db * 16) = pk;
+    for (int rq = 0; rq < RQ; ++rq) {
+        float l_tot = l_run[rq] + __shfl_xor(l_run[rq], 16, 64);
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (qrow_in[rq] < td.q_rows) {
+            bf16_t* orow = O + (size_t)(td.q_row0 + qrow_in[rq]) * o_ts + (size_t)h * D + fg * 4;
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db) {
+                u32x2 pk;
+                pk[0] = pack_bf2(o[rq][db][0] * inv, o[rq][db][1] * inv);
+                pk[1] = pack_bf2(o[rq][db][2] * inv, o[rq][db][3] * inv);
+                *reinterpret_cast<u32x2*>(orow + db * 16) = pk;
+            }
         }
     }
 }
@@ -524,18 +600,26 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 
 }  // namespace
 
-extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int Hq,
-                              int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs,
-                              long v_bs, long o_ts, float scale, hipStream_t stream) {
+extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles,
+                              int rows_per_tile, int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs,
+                              long v_ts, long v_hs, long v_bs, long o_ts, float scale, hipStream_t stream) {
+    if (rows_per_tile != 64 && rows_per_tile != 128) return O3V_ERR_ARG;
     if (!Q || !K || !V || !O || !tiles || n_tiles < 0 || Hq <= 0 || n_rep <= 0 || (Hq % n_rep)) return O3V_ERR_ARG;
     if ((q_ts & 7) || (k_ts & 7) || (v_ts & 7) || (k_hs & 7) || (v_hs & 7) || (o_ts & 3)) return O3V_ERR_SHAPE;
     if (n_tiles == 0) return O3V_OK;
     const float sl2 = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, Hq), block(256);
-#define O3V_AT(DD)                                                                                                    \
-    O3V_KLAUNCH((attn_tiles_kernel<DD>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
+#define O3V_AT1(DD, RQ)                                                                                               \
+    O3V_KLAUNCH((attn_tiles_kernel<DD, RQ>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
                        (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, (const TileDesc*)tiles, q_ts, \
                        k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2)
+#define O3V_AT(DD)                       \
+    do {                                 \
+        if (rows_per_tile == 128)        \
+            O3V_AT1(DD, 2);              \
+        else                             \
+            O3V_AT1(DD, 1);              \
+    } while (0)
     switch (D) {
         case 32: O3V_AT(32); break;
         case 64: O3V_AT(64); break;
@@ -544,6 +628,7 @@ extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void*
         default: return O3V_ERR_SHAPE;
     }
 #undef O3V_AT
+#undef O3V_AT1
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

@@ -85,7 +85,7 @@ extern "C" int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P,
         TRY(o3v_gemm_bf16(h, w.qkv_w, w.qkv_b, nullptr, qkv, P, 3 * hid, hid, hid, hid, 3 * hid, 0, O3V_EPI_NONE, s));
         TRY(o3v_vit_rope(qkv, cosT, sinT, P, H, D, s));
         TRY(o3v_attn_tiles(qkv, qkv + (size_t)hid * 2, qkv + (size_t)2 * hid * 2, att, full ? tiles_full : tiles_win,
-                           full ? n_tiles_full : n_tiles_win, H, 1, D, 3L * hid, 3L * hid, D, 0, 3L * hid, D, 0, hid, scale,
+                           full ? n_tiles_full : n_tiles_win, 64, H, 1, D, 3L * hid, 3L * hid, D, 0, 3L * hid, D, 0, hid, scale,
                            s));
         TRY(o3v_gemm_bf16(att, w.proj_w, w.proj_b, x, x, P, hid, hid, hid, hid, hid, hid, O3V_EPI_RESIDUAL, s));
         TRY(o3v_rmsnorm(x, w.norm2, h, P, hid, hid, hid, 1e-6f, s));
@@ -133,8 +133,8 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
 }  // namespace
 
 extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
-                               int n_tiles, void* kcache, void* vcache, int B, int S, int Tmax, void* workspace,
-                               size_t ws_bytes, o3v_stream_t s) {
+                               int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int Tmax,
+                               void* workspace, size_t ws_bytes, o3v_stream_t s) {
     if (!d || !x || !cosT || !sinT || !tiles || !kcache || !vcache || !workspace) return O3V_ERR_ARG;
     if (B <= 0 || S <= 0 || S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
     const int rows = B * S, H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter;
@@ -150,7 +150,7 @@ extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT,
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
         TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, 0, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
-        TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
+        TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
                            (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
         TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
         TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));

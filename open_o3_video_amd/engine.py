@@ -168,7 +168,7 @@ class O3VEngine:
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         _lib.call("o3v_llm_prefill", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
-                  _ptr(kc), _ptr(vc), B, S, Tmax, _ptr(ws), nbytes, _stream())
+                  indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, Tmax, _ptr(ws), nbytes, _stream())
         return x
 
     def head(self, x_rows: torch.Tensor) -> torch.Tensor:

@@ -11,7 +11,8 @@ from functools import lru_cache
 
 import numpy as np
 
-TILE = 64  # query rows per attention tile (csrc/o3v_attn.hip)
+TILE = 64           # query rows per attention tile for the ragged ViT segments (csrc/o3v_attn.hip, RQ = 1)
+PREFILL_TILE = 128  # query rows per tile of the causal prefill (RQ = 2: two 16-row blocks per wave)
 
 
 def _grid_key(grid_thw):
@@ -65,13 +66,13 @@ def segment_tiles(cu):
     return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
 
-def prefill_tiles(B, S, pad):
+def prefill_tiles(B, S, pad, tile=PREFILL_TILE):
     """Causal tiles over B left-padded rows of S tokens whose K/V sit in the cache at slots 0..S-1."""
     out = []
     for b in range(B):
         pb = int(pad[b])
-        for q0 in range((pb // TILE) * TILE, S, TILE):
-            out.append((b * S + q0, min(TILE, S - q0), 0, S, q0, pb, b, 0))
+        for q0 in range((pb // tile) * tile, S, tile):
+            out.append((b * S + q0, min(tile, S - q0), 0, S, q0, pb, b, 0))
     return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
 

@@ -41,8 +41,8 @@ def vit_rope_(qkv, cos, sin, H, D):
     return qkv
 
 
-def attn_tiles(q, k, v, tiles, Hq, n_rep, D, q_ts, k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, out, o_ts, scale):
-    _lib.call("o3v_attn_tiles", _p(q), _p(k), _p(v), _p(out), _p(tiles), tiles.shape[0], Hq, n_rep, D, q_ts, k_ts, k_hs,
+def attn_tiles(q, k, v, tiles, Hq, n_rep, D, q_ts, k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, out, o_ts, scale, rows_per_tile=64):
+    _lib.call("o3v_attn_tiles", _p(q), _p(k), _p(v), _p(out), _p(tiles), tiles.shape[0], rows_per_tile, Hq, n_rep, D, q_ts, k_ts, k_hs,
               k_bs, v_ts, v_hs, v_bs, o_ts, float(scale), _s())
     return out
 

@@ -341,17 +341,18 @@ def test_attn_varlen_noncausal(dev, H, D, lens):
 
 @pytest.mark.parametrize("Hq,Hkv,D,S,pads", [(7, 1, 128, 150, [0, 13]), (4, 2, 32, 70, [5]), (16, 2, 128, 333, [0]),
                                              (4, 4, 64, 129, [64, 0, 127])])
-def test_attn_causal_gqa_prefill(dev, Hq, Hkv, D, S, pads):
+@pytest.mark.parametrize("tile", [64, 128])
+def test_attn_causal_gqa_prefill(dev, Hq, Hkv, D, S, pads, tile):
     from open_o3_video_amd import ops, indexing
     B, Tmax = len(pads), S + 9
     g = torch.Generator().manual_seed(S + D)
     q = torch.randn(B, S, Hq, D, generator=g).to(BF)
     k = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
     v = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
-    tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pads)).to(dev)
+    tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pads, tile)).to(dev)
     out = torch.zeros(B * S, Hq * D, dtype=BF, device=dev)
     ops.attn_tiles(q.reshape(B * S, -1).to(dev), k.to(dev), v.to(dev), tiles, Hq, Hq // Hkv, D, Hq * D, D, Tmax * D,
-                   Hkv * Tmax * D, D, Tmax * D, Hkv * Tmax * D, out, Hq * D, D ** -0.5)
+                   Hkv * Tmax * D, D, Tmax * D, Hkv * Tmax * D, out, Hq * D, D ** -0.5, rows_per_tile=tile)
     out = out.view(B, S, Hq, D).cpu()
     rep = Hq // Hkv
     for b, pad in enumerate(pads):

@@ -65,8 +65,9 @@ def test_tiles():
     t = indexing.segment_tiles(np.asarray([0, 12, 76, 206]))
     assert t.tolist() == [[0, 12, 0, 12, -1, 0, 0, 0], [12, 64, 12, 64, -1, 0, 0, 0], [76, 64, 76, 130, -1, 0, 0, 0],
                           [140, 64, 76, 130, -1, 0, 0, 0], [204, 2, 76, 130, -1, 0, 0, 0]]
-    p = indexing.prefill_tiles(2, 100, [0, 70])
+    p = indexing.prefill_tiles(2, 100, [0, 70], 64)
     assert p.tolist() == [[0, 64, 0, 100, 0, 0, 0, 0], [64, 36, 0, 100, 64, 0, 0, 0], [164, 36, 0, 100, 64, 70, 1, 0]]
+    assert indexing.prefill_tiles(1, 300, [130]).tolist() == [[128, 128, 0, 300, 128, 130, 0, 0], [256, 44, 0, 300, 256, 130, 0, 0]]
     assert indexing.segment_tiles(np.asarray([0])).shape == (0, 8)
 
 
@@ -129,8 +130,9 @@ def test_c_abi_argument_errors_without_gpu():
     assert lib.o3v_gemv_bf16(p, p, None, None, p, 9, 8, 64, 64, 64, 8, 0, 0, None) == _lib.ERR_SHAPE
     assert lib.o3v_gemm_bf16(p, p, None, None, p, 0, 8, 64, 64, 64, 8, 0, 0, None) == _lib.OK  # empty input
     assert lib.o3v_rmsnorm(p, p, p, 0, 64, 64, 64, 1e-6, None) == _lib.OK
-    assert lib.o3v_attn_tiles(p, p, p, p, p, 0, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.OK
-    assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 4, 1, 48, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_SHAPE
+    assert lib.o3v_attn_tiles(p, p, p, p, p, 0, 64, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.OK
+    assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 64, 4, 1, 48, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_SHAPE
+    assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 96, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_ARG
 
 
 def test_engine_refuses_to_run_without_gpu():
