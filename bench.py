@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--res", default="train", choices=["train", "eval"])
     ap.add_argument("--model", default="7b", choices=["7b", "3b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra 8-videos-per-step throughput measurement")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -199,7 +200,7 @@ def main():
     cfg_dict = qwen25vl_7b_dict() if args.model == "7b" else qwen25vl_3b_dict()
     cfg = O3VConfig.from_dict(cfg_dict)
     dev = torch.device("cuda", local_rank)
-    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=False))  # B=1: row-major only
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=not args.no_batched))
     Hres, Wres = (224, 420) if args.res == "train" else (364, 644)
     tpf = (Hres // 28) * (Wres // 28)
     S = 4490 if args.res == "train" else 10218
@@ -237,6 +238,27 @@ def main():
 
     # per-stage breakdown (one extra, untimed, synchronised step)
     stages = step(0, timings=True).timings
+
+    # extra (not `value`): throughput with 8 videos decoding together per GPU -- the eval path of the reference runs a
+    # vLLM engine with max_num_seqs=5 (R:eval/models/model_vllm.py:23), i.e. it batches concurrent requests too.  Decode is
+    # weight-bandwidth-bound, so the 8 sequences share every streamed weight byte (MFMA skinny-GEMM path).
+    batched = None
+    if not args.no_batched:
+        NB = 8
+        vids8 = torch.randint(0, 256, (NB * args.frames, 3, Hres, Wres), generator=gen, dtype=torch.uint8, device=dev)
+
+        def step8():
+            return eng.generate([ids] * NB, None, frames=vids8, max_new_tokens=args.new_tokens, eos_token_ids=(),
+                                repetition_penalty=1.05, return_margins=False)
+        step8()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        o8 = step8()
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        assert o8.sequences.shape == (NB, S + args.new_tokens)
+        batched = {"videos_per_step": NB, "tokens_per_s_per_gpu": round(NB * args.new_tokens / tb, 1),
+                   "videos_per_min_per_gpu": round(NB / tb * 60.0, 1), "ms_per_step": round(tb * 1e3, 1)}
     roof = None if args.no_roofline else kernel_roofline(eng)
 
     if rank == 0:
@@ -262,6 +284,8 @@ def main():
                                 "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
                                 "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None},
         }
+        if batched:
+            rec["batched_8_videos"] = batched
         if roof:
             rec["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
