@@ -165,9 +165,12 @@ int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P, const int*
 
 size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 /* Qwen2_5_VLTextModel.forward over the prompt, TF:790-872: x bf16 [B*S,H] holds inputs_embeds on entry and the
- * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D]. */
+ * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D].
+ * past > 0: the caches already hold `past` tokens per row (a shared prompt prefix, TF cache semantics of
+ * `past_key_values`: DynamicCache.update appends); the S new tokens land in slots past..past+S-1 and the causal
+ * tiles carry causal_off = past + q0, k_len = past + S. */
 int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
-                    int rows_per_tile, void* kcache, void* vcache, int B, int S, int Tmax, void* workspace,
+                    int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax, void* workspace,
                     size_t ws_bytes, o3v_stream_t stream);
 /* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
 int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,

@@ -73,7 +73,7 @@ SIGNATURES = {
     "o3v_vit_workspace_bytes": [C.POINTER(VitDesc), i32],
     "o3v_vit_forward": [C.POINTER(VitDesc), vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, sz, vp, vp],
     "o3v_llm_workspace_bytes": [C.POINTER(LlmDesc), i32],
-    "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, sz, vp],
+    "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp],
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }

@@ -133,10 +133,10 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
 }  // namespace
 
 extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
-                               int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int Tmax,
-                               void* workspace, size_t ws_bytes, o3v_stream_t s) {
+                               int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int past,
+                               int Tmax, void* workspace, size_t ws_bytes, o3v_stream_t s) {
     if (!d || !x || !cosT || !sinT || !tiles || !kcache || !vcache || !workspace) return O3V_ERR_ARG;
-    if (B <= 0 || S <= 0 || S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
+    if (B <= 0 || S <= 0 || past < 0 || past + S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
     const int rows = B * S, H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter;
     const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
     LlmWs w;
@@ -149,7 +149,7 @@ extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT,
         char* vc = (char*)vcache + l * layer_stride;
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
-        TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, 0, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
+        TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
         TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
                            (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
         TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));

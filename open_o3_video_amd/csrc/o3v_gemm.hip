@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
 // blocks j and j + D/2), the 4 waves of a block either take 4 different row groups (KS = 1) or split K (KS = 4).
 // NORM: RMSNorm of x fused, normalised rows kept in LDS with a 16-byte row skew (conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool NORM, int KS, bool PACKED>
+template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int b = 0; b < RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool has_x = fr < M;
-    constexpr int U = 8 / RB;  // 8 KiB of weight loads in flight per wave and trip
+    constexpr int U = UT / RB;  // UT KiB of weight loads in flight per wave and trip
     for (int s0 = s_begin; s0 < s_end; s0 += U) {
         bf16x8 wf[U][RB], xf[U];
 #pragma unroll
@@ -829,6 +829,14 @@ static int launch_gemv_mfma_t(const GemvArgs& a, int M) {
     return launch_gemv_mfma_p<EPI, NORM, KS, false>(a, M);
 }
 
+#ifdef O3V_TUNE
+static int g_mt_ks = 0, g_mt_ut = 0;
+extern "C" void o3v_gemv_mfma_tune(int ks, int ut) {
+    g_mt_ks = ks;
+    g_mt_ut = ut;
+}
+#endif
+
 template <int EPI, bool NORM, int KS, bool PACKED>
 static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
@@ -836,15 +844,33 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     constexpr int RG = 4 / KS;
     dim3 grid((groups + RG - 1) / RG), block(256);
     const size_t shmem = (NORM ? (size_t)M * (a.K * 2 + 16) : 0) + (KS > 1 ? (size_t)4 * RB * 64 * 16 : 0) + (NORM ? 16 * 4 * 4 : 0);
-    O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, a.eps, M,
-                a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+#ifdef O3V_TUNE
+    if (g_mt_ut == 16) {
+        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 16>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
+                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+        return O3V_OK;
+    }
+    if (g_mt_ut == 4) {
+        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 4>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
+                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+        return O3V_OK;
+    }
+#endif
+    // 16 KiB of weight loads in flight per wave for the single-block epilogues, 8 KiB for the paired (gate/up, q/k/v) ones:
+    // A/B on the 7B shapes in profiles/r01_m8_linear.txt
+    constexpr int UT = RB == 1 ? 16 : 8;
+    O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, UT>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, a.eps,
+                M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
     return O3V_OK;
 }
 
 static int launch_gemv_mfma(const GemvArgs& a, int M) {
     const int groups = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 32 : (a.N + 15) / 16;
     // wave tasks = row groups x K slices: aim at >= 2048 waves (8 per CU) so enough weight loads are in flight
-    const int ks = groups >= 2048 ? 1 : (groups >= 1024 ? 2 : 4);
+    int ks = groups >= 2048 ? 1 : (groups >= 1024 ? 2 : 4);
+#ifdef O3V_TUNE
+    if (g_mt_ks) ks = g_mt_ks;
+#endif
 #define O3V_MK(E, NRM)                                                       \
     do {                                                                     \
         if (ks == 1) return launch_gemv_mfma_t<E, NRM, 1>(a, M);             \

@@ -142,11 +142,13 @@ class O3VEngine:
         _lib.call("o3v_mrope_table", _ptr(p), _ptr(self.inv_freq), _ptr(self.axis_of), _ptr(cos), _ptr(sin), T, D, _stream())
         return cos, sin
 
-    def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor]) -> torch.Tensor:
+    def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor], first: int = 0) -> torch.Tensor:
+        """inputs_embeds of the (flattened) prompt; `first` > 0 returns only rows first.. (prefix-KV reuse)."""
         src, n_img = indexing.embed_source_rows(input_ids, self.cfg.image_token_id)
         if n_img and (vis is None or vis.shape[0] != n_img):
             raise ValueError(f"Image features and image tokens do not match, tokens: {n_img}, "
                              f"features: {0 if vis is None else vis.shape[0]}")
+        src = src[first:]
         H = self.cfg.text.hidden_size
         T = src.shape[0]
         x = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
@@ -160,15 +162,17 @@ class O3VEngine:
         return (torch.empty(shape, dtype=torch.bfloat16, device=self.dev),
                 torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
 
-    def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc):
-        """Runs the prompt through the LLM (TF:790-872); x [B*S,H] becomes the last layer's residual stream."""
+    def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc, past: int = 0):
+        """Runs the prompt through the LLM (TF:790-872); x [B*S,H] becomes the last layer's residual stream.
+        past > 0: slots 0..past-1 of the caches already hold a prompt prefix (HF `past_key_values` semantics);
+        x / pos3 are the S tokens after it."""
         Tmax = kc.shape[3]
         cos, sin = self.mrope_table(pos3.reshape(3, B * S))
-        tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad)).to(self.dev)
+        tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad, past=past)).to(self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         _lib.call("o3v_llm_prefill", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
-                  indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, Tmax, _ptr(ws), nbytes, _stream())
+                  indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, int(past), Tmax, _ptr(ws), nbytes, _stream())
         return x
 
     def head(self, x_rows: torch.Tensor) -> torch.Tensor:
@@ -187,9 +191,15 @@ class O3VEngine:
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
                  vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 32, return_margins: bool = True,
-                 sync_timings: bool = False) -> GenerateOutput:
+                 sync_timings: bool = False, prefix_key=None) -> GenerateOutput:
         """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
-        completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out."""
+        completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out.
+
+        `prefix_key` (hashable, single un-padded prompt only): identifies the visual content of the prompt.  The
+        K/V of the prompt is kept under that key; a later call with the same key prefills only the tokens after
+        the longest common token prefix (V-STAR asks 5 questions per video with the frame block first,
+        R:eval/test/test_vstar_multi_images.py:205-206,511-544; self-consistency draws N samples of one prompt,
+        R:eval/tts.py:47-123).  Causal attention makes the prefix K/V independent of what follows it."""
         cfg, tc = self.cfg, self.cfg.text
         ids = np.asarray(input_ids.cpu() if torch.is_tensor(input_ids) else input_ids, dtype=np.int64)
         if ids.ndim == 1:
@@ -233,17 +243,28 @@ class O3VEngine:
             pos, deltas = np.broadcast_to(p1[None], (3, B0, S)).copy(), np.zeros(B0, dtype=np.int64)
         Tmax = S + T
         kc, vc = self.alloc_cache(B, Tmax)
-        x = self.embed(ids, vis)
-        if G == 1:
+        past = 0
+        use_prefix = prefix_key is not None and B0 == 1 and int(pad[0]) == 0
+        if use_prefix:
+            past = self._prefix_lookup(prefix_key, ids[0])
+        x = self.embed(ids, vis, first=past)
+        if G == 1 and not use_prefix:
             self.prefill(x, pos, pad, B0, S, kc, vc)
         else:
-            kc0, vc0 = self.alloc_cache(B0, Tmax)
-            self.prefill(x, pos, pad, B0, S, kc0, vc0)
+            kc0, vc0 = self.alloc_cache(B0, S)
+            if past:
+                ent = self._prefix[prefix_key]
+                kc0[:, :, :, :past].copy_(ent["k"][:, :, :, :past])
+                vc0[:, :, :, :past].copy_(ent["v"][:, :, :, :past])
+            self.prefill(x, pos[:, :, past:], pad, B0, S - past, kc0, vc0, past=past)
             # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
-            kc[:, :, :, :S].copy_(kc0[:, :, :, :S].repeat_interleave(G, dim=1))
-            vc[:, :, :, :S].copy_(vc0[:, :, :, :S].repeat_interleave(G, dim=1))
+            kc[:, :, :, :S].copy_(kc0.repeat_interleave(G, dim=1) if G > 1 else kc0)
+            vc[:, :, :, :S].copy_(vc0.repeat_interleave(G, dim=1) if G > 1 else vc0)
+            if use_prefix:
+                self._prefix_store(prefix_key, ids[0], kc0, vc0)
             del kc0, vc0
-        last = x.view(B0, S, -1)[:, -1, :]                      # left padding: every row ends at S-1
+        tm["prefix_tokens_reused"] = past
+        last = x.view(B0, S - past, -1)[:, -1, :]               # left padding: every row ends at S-1
         logits0 = self.head(last)                               # [B0, V]
         logits = logits0.repeat_interleave(G, dim=0).contiguous() if G > 1 else logits0
         mark(2)
@@ -306,10 +327,35 @@ class O3VEngine:
         seqs = torch.cat([prompt, gen], dim=1)
         if ev is not None:
             torch.cuda.synchronize()
-            tm = {"vit_ms": ev[0].elapsed_time(ev[1]), "prefill_ms": ev[1].elapsed_time(ev[2]),
-                  "decode_ms": ev[2].elapsed_time(ev[3])}
+            tm.update({"vit_ms": ev[0].elapsed_time(ev[1]), "prefill_ms": ev[1].elapsed_time(ev[2]),
+                       "decode_ms": ev[2].elapsed_time(ev[3])})
         return GenerateOutput(sequences=seqs, margins=None if margins is None else margins[:, :done], n_steps=done,
                               timings=tm)
+
+    # ------------------------------------------------------------------------------------------ prefix K/V
+    PREFIX_ENTRIES = 2   # videos whose prompt K/V stay resident (7B, S=4.5k: 0.26 GB each; 288 GB HBM is not the limit)
+
+    def _prefix_lookup(self, key, ids_row: np.ndarray) -> int:
+        """Tokens of `ids_row` whose K/V are cached under `key`: the longest common prefix, capped at S-1 so the
+        last prompt token is always run (its hidden state feeds the first logits)."""
+        ent = getattr(self, "_prefix", {}).get(key)
+        if ent is None:
+            return 0
+        old = ent["ids"]
+        n = min(len(old), len(ids_row) - 1)
+        neq = np.flatnonzero(old[:n] != ids_row[:n])
+        return int(neq[0]) if neq.size else int(n)
+
+    def _prefix_store(self, key, ids_row: np.ndarray, kc0, vc0):
+        if not hasattr(self, "_prefix"):
+            self._prefix = {}
+        self._prefix.pop(key, None)
+        while len(self._prefix) >= self.PREFIX_ENTRIES:
+            self._prefix.pop(next(iter(self._prefix)))
+        self._prefix[key] = {"ids": np.array(ids_row, copy=True), "k": kc0, "v": vc0}
+
+    def drop_prefix_cache(self):
+        self._prefix = {}
 
     @staticmethod
     def _first_all_finished(gen: torch.Tensor, eos_ids, pad_id) -> int:

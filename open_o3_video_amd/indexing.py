@@ -66,13 +66,16 @@ def segment_tiles(cu):
     return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
 
-def prefill_tiles(B, S, pad, tile=PREFILL_TILE):
-    """Causal tiles over B left-padded rows of S tokens whose K/V sit in the cache at slots 0..S-1."""
+def prefill_tiles(B, S, pad, tile=PREFILL_TILE, past=0):
+    """Causal tiles over B left-padded rows of S new tokens whose K/V sit in the cache at slots past..past+S-1
+    (slots 0..past-1 hold an already-computed prompt prefix; `pad` counts the left padding inside that prefix
+    when past > 0, inside the new tokens otherwise)."""
     out = []
     for b in range(B):
         pb = int(pad[b])
-        for q0 in range((pb // tile) * tile, S, tile):
-            out.append((b * S + q0, min(tile, S - q0), 0, S, q0, pb, b, 0))
+        first = 0 if past else (pb // tile) * tile
+        for q0 in range(first, S, tile):
+            out.append((b * S + q0, min(tile, S - q0), 0, past + S, past + q0, pb, b, 0))
     return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
 

@@ -64,7 +64,8 @@ class LLM:
     def __init__(self, model: str = None, tensor_parallel_size: int = 1, max_model_len: int = 81920,
                  gpu_memory_utilization: float = 0.9, limit_mm_per_prompt: Optional[dict] = None, dtype: str = "bfloat16",
                  max_num_seqs: int = 8, engine: Optional[O3VEngine] = None, tokenizer: Any = None,
-                 min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda", **_):
+                 min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda",
+                 enable_prefix_caching: bool = True, **_):
         if tensor_parallel_size != 1:
             raise ValueError("the reference runs tensor_parallel_size=1 (R:eval/models/model_vllm.py:21); data parallelism "
                              "is one engine per GPU (open_o3_video_amd.dist)")
@@ -97,6 +98,10 @@ class LLM:
         self._vis_cache = {}
         self.vis_cache_size = 4
         self.vis_cache_hits = 0
+        # prompt-prefix K/V reuse per video (same section): only the tokens after the longest common token prefix of two
+        # prompts over identical frames are prefilled; vLLM's `enable_prefix_caching` keyword switches it
+        self.enable_prefix_caching = bool(enable_prefix_caching)
+        self.prefix_tokens_reused = 0
 
     # ---- multimodal input -> uint8/f32 frames [T,3,H,W] with H,W multiples of 28
     def _frames(self, mm) -> Optional[torch.Tensor]:
@@ -145,13 +150,13 @@ class LLM:
         hit = self._vis_cache.get(key)
         if hit is not None:
             self.vis_cache_hits += 1
-            return hit
+            return hit, key
         px, grid = self.engine.pixels_from_frames(fr)
         vis = self.engine.vit_forward(px, grid)
         if len(self._vis_cache) >= self.vis_cache_size:
             self._vis_cache.pop(next(iter(self._vis_cache)))
         self._vis_cache[key] = vis
-        return vis
+        return vis, key
 
     def _tokenize(self, prompt: str, n_frames: int, tok_per_frame: int):
         if n_frames:
@@ -177,24 +182,31 @@ class LLM:
             greedy = sp.temperature == 0.0
             stop = list(sp.stop_token_ids) if sp.stop_token_ids else []
             eos = stop + ([self.cfg.eos_token_id] if self.cfg.eos_token_id is not None else [])
-            vis, grid = None, None
+            vis, grid, vkey = None, None, ("text-only",)
             if frames is not None:
-                vis = self._visual_tokens(frames)
+                vis, vkey = self._visual_tokens(frames)
                 grid = np.asarray([[1, frames.shape[2] // 14, frames.shape[3] // 14]] * frames.shape[0], dtype=np.int64)
-            out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=sp.max_tokens, eos_token_ids=eos,
-                                       pad_token_id=self.cfg.pad_token_id, repetition_penalty=sp.repetition_penalty,
-                                       do_sample=not greedy, temperature=1.0 if greedy else sp.temperature,
-                                       top_p=1.0 if greedy else sp.top_p, num_return_sequences=sp.n,
-                                       seed=self._req if sp.seed is None else sp.seed, return_margins=False)
             ro = RequestOutput(request_id=str(self._req), prompt=prompt, prompt_token_ids=ids)
-            for i in range(sp.n):
-                toks = out.sequences[i, len(ids):].tolist()
-                reason = "length"
-                for j, t in enumerate(toks):
-                    if t in eos:
-                        toks, reason = toks[:j], "stop"   # vLLM drops the stop token from the text
-                        break
-                ro.outputs.append(CompletionOutput(i, self.tokenizer.decode(toks, skip_special_tokens=True), toks, reason))
+            # n samples of one prompt (self-consistency, R:eval/tts.py:47-123) run in groups of <= 8 decode rows; sample i is
+            # keyed by (seed, i) whatever group it lands in, and groups after the first reuse the whole prompt K/V
+            for i0 in range(0, sp.n, 8):
+                g = min(8, sp.n - i0)
+                out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=sp.max_tokens,
+                                           eos_token_ids=eos, pad_token_id=self.cfg.pad_token_id,
+                                           repetition_penalty=sp.repetition_penalty, do_sample=not greedy,
+                                           temperature=1.0 if greedy else sp.temperature, top_p=1.0 if greedy else sp.top_p,
+                                           num_return_sequences=g, row_ids=list(range(i0, i0 + g)),
+                                           seed=self._req if sp.seed is None else sp.seed, return_margins=False,
+                                           prefix_key=vkey if self.enable_prefix_caching else None)
+                self.prefix_tokens_reused += int(out.timings.get("prefix_tokens_reused", 0))
+                for i in range(g):
+                    toks = out.sequences[i, len(ids):].tolist()
+                    reason = "length"
+                    for j, t in enumerate(toks):
+                        if t in eos:
+                            toks, reason = toks[:j], "stop"   # vLLM drops the stop token from the text
+                            break
+                    ro.outputs.append(CompletionOutput(i0 + i, self.tokenizer.decode(toks, skip_special_tokens=True), toks, reason))
             results.append(ro)
             self._req += 1
         return results

@@ -139,6 +139,20 @@ def test_vllm_facade(need_gpu, golden_dir):
     o5 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}},
                       SamplingParams(temperature=0.7, top_p=0.9, repetition_penalty=1.05, max_tokens=8, n=3, seed=3))
     assert len(o5[0].outputs) == 3
+    # prompts over identical frames reused their common prefix K/V (o3, o4 and o5 repeat the first prompt)
+    assert llm.prefix_tokens_reused >= 3 * (len(ids) - 1)
+    # n > 8 samples run as groups of <= 8 rows; sample i depends on (seed, i) only
+    sp10 = SamplingParams(temperature=1.0, top_p=0.95, repetition_penalty=1.05, max_tokens=6, n=10, seed=11)
+    o6 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}}, sp10)[0].outputs
+    sp4 = SamplingParams(temperature=1.0, top_p=0.95, repetition_penalty=1.05, max_tokens=6, n=4, seed=11)
+    o7 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}}, sp4)[0].outputs
+    assert [o.index for o in o6] == list(range(10)) and len({tuple(o.token_ids) for o in o6}) > 1
+    assert all(o6[i].token_ids == o7[i].token_ids for i in range(4))
+    # switching the reuse off gives the same greedy tokens
+    llm2 = LLM(engine=eng, tokenizer=StubTokenizer(cfg), limit_mm_per_prompt={"image": 32}, max_model_len=4096,
+               enable_prefix_caching=False)
+    o8 = llm2.generate([{"prompt": prompt, "multi_modal_data": {"image": frames}}] * 2, sampling_params=sp)
+    assert o8[0].outputs[0].token_ids == exp and o8[1].outputs[0].token_ids == exp and llm2.prefix_tokens_reused == 0
 
 
 def test_group_rollout_step(need_gpu, golden_dir):

@@ -178,3 +178,45 @@ def test_group_rollout_shares_prefill(need_gpu):
     s3 = eng.generate([ids], None, frames=fr, max_new_tokens=12, num_return_sequences=2, do_sample=True, top_p=0.95,
                       temperature=1.0, seed=7, row_ids=[2, 3]).sequences
     assert torch.equal(s3, s1[2:4])
+
+
+def test_prefix_kv_reuse(need_gpu, golden_dir):
+    """SURVEY 8f-1 (several questions / samples per video, R:eval/test/test_vstar_multi_images.py:511-544): with a
+    `prefix_key` only the tokens after the longest common prefix are prefilled.  Greedy ids must equal the cold run
+    and the HF golden wherever the cut falls (GEMV-sized suffix, GEMM-sized suffix, cut before the frame block)."""
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 2))
+    pv = torch.from_numpy(g["pixel_values"])
+    ids = g["input_ids"][0].copy()
+    S = len(ids)
+    special = {cfg["image_token_id"], cfg["vision_start_token_id"], cfg["vision_end_token_id"]}
+    text_pos = [i for i in range(S) if int(ids[i]) not in special]
+    kw = dict(pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=16, repetition_penalty=1.05,
+              pad_token_id=cfg["pad_token_id"])
+    cold = eng.generate([ids], None, **kw)
+    exp = g["bf16_ids_rp105"]
+    assert np.array_equal(cold.sequences.cpu().numpy(), exp)
+    assert cold.timings["prefix_tokens_reused"] == 0
+    cuts = [text_pos[-3], max(p for p in text_pos if p <= S - 20), text_pos[1]]
+    for n, cut in enumerate(cuts):
+        other = ids.copy()
+        other[cut] = ids[cut] + 1 if int(ids[cut]) + 1 not in special else ids[cut] + 2
+        eng.generate([other], None, prefix_key=("vid", n), **{**kw, "max_new_tokens": 2})       # a first question
+        warm = eng.generate([ids], None, prefix_key=("vid", n), **kw)                            # the next one
+        assert warm.timings["prefix_tokens_reused"] == cut, (cut, warm.timings)
+        assert np.array_equal(warm.sequences.cpu().numpy(), exp), f"cut at {cut} of {S}"
+    # same prompt again (a second group of samples): everything but the last token is reused, rows fan out
+    again = eng.generate([ids], None, prefix_key=("vid", len(cuts) - 1), num_return_sequences=3, **kw)
+    assert again.timings["prefix_tokens_reused"] == S - 1
+    assert all(np.array_equal(again.sequences[i].cpu().numpy(), exp[0]) for i in range(3))
+    # an unknown key is a cold run and does not disturb the result
+    fresh = eng.generate([ids], None, prefix_key="another video", **kw)
+    assert fresh.timings["prefix_tokens_reused"] == 0 and np.array_equal(fresh.sequences.cpu().numpy(), exp)
+    # logits of the suffix pass against the full pass (same tolerance as the full pass against HF)
+    eng.drop_prefix_cache()
+    full = eng.forward_logits(ids[None], None, pixel_values=pv, image_grid_thw=g["grid"])[0, -1].float()
+    eng.generate([ids], None, prefix_key="v", **{**kw, "max_new_tokens": 1})
+    assert eng._prefix_lookup("v", ids) == S - 1
+    ref = torch.from_numpy(g["f32_prefill_last_logits"])[0]
+    assert (full.cpu() - ref).abs().max().item() < LOGIT_ATOL

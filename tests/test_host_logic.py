@@ -69,6 +69,8 @@ def test_tiles():
     assert p.tolist() == [[0, 64, 0, 100, 0, 0, 0, 0], [64, 36, 0, 100, 64, 0, 0, 0], [164, 36, 0, 100, 64, 70, 1, 0]]
     assert indexing.prefill_tiles(1, 300, [130]).tolist() == [[128, 128, 0, 300, 128, 130, 0, 0], [256, 44, 0, 300, 256, 130, 0, 0]]
     assert indexing.segment_tiles(np.asarray([0])).shape == (0, 8)
+    # suffix pass behind a cached prompt prefix of 1000 tokens: queries are rows 0..149, keys slots 0..1149
+    assert indexing.prefill_tiles(1, 150, [0], past=1000).tolist() == [[0, 128, 0, 1150, 1000, 0, 0, 0], [128, 22, 0, 1150, 1128, 0, 0, 0]]
 
 
 def test_embed_source_rows():

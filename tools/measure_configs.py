@@ -47,6 +47,42 @@ if "rollout" in which:
 if "long" in which:
     run("LONG 256x224x224 greedy B=1", 256, 224, 224, 256 * (64 + 15) + 170, 128, repetition_penalty=1.05)
 
+if "vstar5" in which:
+    # the V-STAR harness asks 5 questions per video (R:eval/test/test_vstar_multi_images.py:511-544); frame
+    # block first, then a ~64-token question; 128 greedy tokens each.  With / without visual + prefix-K/V reuse.
+    tpf = (224 // 28) * (420 // 28)
+    base = build_prompt(cfg, 32, tpf, 4490)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (32, 3, 224, 420), generator=g, dtype=torch.uint8, device=dev)
+    rng = __import__("numpy").random.default_rng(5)
+    qs = []
+    for q in range(5):
+        ids = list(base)
+        ids[-64:] = [int(t) for t in rng.integers(1000, 150000, 64)]
+        qs.append(ids)
+    for reuse in (False, True):
+        eng.drop_prefix_cache()
+        eng.generate([qs[0]], None, frames=frames, max_new_tokens=4)  # warm-up (code paths, allocator)
+        eng.drop_prefix_cache()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vis, reused = None, 0
+        for ids in qs:
+            if reuse and vis is None:
+                px, grid = eng.pixels_from_frames(frames)
+                vis = eng.vit_forward(px, grid)
+            if reuse:
+                out = eng.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=128, repetition_penalty=1.05,
+                                   prefix_key="video", return_margins=False)
+            else:
+                out = eng.generate([ids], None, frames=frames, max_new_tokens=128, repetition_penalty=1.05, return_margins=False)
+            reused += out.timings["prefix_tokens_reused"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": f"V-STAR 5 questions/video, 128 tok each, reuse={reuse}", "S": len(base), "wall_s": round(dt, 3),
+                          "videos_per_min": round(60 / dt, 1), "questions_per_s": round(5 / dt, 2),
+                          "prefix_tokens_reused": int(reused)}), flush=True)
+
 if "3b" in which:
     # BASELINE config #1 shapes: Qwen2.5-VL-3B dims (tied embeddings, GQA 8:1), 4 frames at EVAL-RES, 256 new tokens
     from open_o3_video_amd.config import qwen25vl_3b_dict
