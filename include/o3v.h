@@ -102,6 +102,14 @@ int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const i
 int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                     const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
                     o3v_stream_t stream);
+/* The same for B = (B/G) groups of G rows whose first `prefix_len` keys are identical (the G completions of one
+ * prompt: `num_return_sequences`, R:grpo_trainer.py:306-313, TF:1493-1579 `_expand_inputs_for_generation`; the n
+ * samples of R:eval/tts.py:47-123).  The prefix K/V are read ONCE per group, from the cache row of the group's first
+ * sequence, with the G*Hq/Hkv (<= 64) query rows of a kv head sharing every key tile; each row's own keys
+ * prefix_len..ctx-1 come from its own cache row.  head_dim 128 only.  part_o/part_ml: 64 splits per (row, head). */
+int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
+                          const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
+                          int nsplit_prefix, float scale, o3v_stream_t stream);
 
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
@@ -199,6 +207,8 @@ typedef struct {
     void *workspace; size_t ws_bytes;
     o3v_stream_t side_stream;    /* optional: weight prefetch runs here beside the decode attention (NULL = off) */
     size_t prefetch_bytes;       /* bytes of the next projections' weights to pull on-die per layer */
+    int group;                   /* > 1: rows g*group..g*group+group-1 share their first S keys -> o3v_attn_decode_group
+                                    (nsplit is then the prefix split count; part_o/part_ml hold 64 splits) */
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
                                                                int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
-                                                               float scale_log2e) {
+                                                               float scale_log2e, int kbeg, int nsplit_tot, int split_off,
+                                                               int G, int P) {
+    // keys kbeg..ctx-1 of every row; partials go to slots split_off.. of the row's nsplit_tot (the slots before
+    // split_off belong to attn_decode_group_kernel when the rows of a group share their first kbeg keys)
     constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE;  // 9216 B per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];               // 4 x V slice, reused for the merge
     const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b = blockIdx.z;
@@ -437,10 +440,10 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
     const int k_lo = k_lo_arr ? k_lo_arr[b] : 0;
     char* Vl = smem + wave * V_BYTES;
 
-    int chunk = (ctx + nsplit - 1) / nsplit;
+    int chunk = (ctx - kbeg + nsplit - 1) / nsplit;
     chunk = (chunk + 4 * KT - 1) / (4 * KT) * (4 * KT);  // whole 32-key tiles per wave
     const int per_wave = chunk >> 2;
-    const int kw0 = split * chunk + wave * per_wave;
+    const int kw0 = kbeg + split * chunk + wave * per_wave;
     int kw1 = kw0 + per_wave;
     kw1 = kw1 < ctx ? kw1 : ctx;
 
@@ -454,6 +457,11 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
     }
     const bf16_t* Kb = Kc + (size_t)b * k_bs + (size_t)hk * k_hs;
     const bf16_t* Vb = Vc + (size_t)b * k_bs + (size_t)hk * k_hs;
+    // G > 1: keys below P are read from the cache row of the group's first sequence (identical bytes for the G rows of a
+    // group, whose blocks share an XCD and hence an L2: one HBM read serves the group)
+    const size_t lead = G > 1 ? (size_t)(b - (b / G) * G) * k_bs : 0;
+    const bf16_t* Kl = Kb - lead;
+    const bf16_t* Vl0 = Vb - lead;
 
     float m_run = -1e30f, l_run = 0.f;
     f32x4 o[8];
@@ -468,9 +476,9 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
         for (int kb = 0; kb < 2; ++kb) {
             int kr = key0 + kb * 16 + fr;
             kr = kr < ctx ? kr : ctx - 1;
+            const bf16_t* Kr = (kr < P ? Kl : Kb) + (size_t)kr * D;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Kb + (size_t)kr * D + ks * 32 + fg * 8);
+            for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Kr + ks * 32 + fg * 8);
         }
         // ---- V tile -> this wave's LDS slice (32 rows x 16 chunks of 16 B, 8 per lane)
         u32x4 vreg[8];
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
             const int c = i * 64 + lane, row = c >> 4, ch = c & 15;
             int kr = key0 + row;
             kr = kr < ctx ? kr : ctx - 1;
-            vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (size_t)kr * D + ch * 8);
+            vreg[i] = *reinterpret_cast<const u32x4*>((kr < P ? Vl0 : Vb) + (size_t)kr * D + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -561,11 +569,195 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
             acc += so[(size_t)(w * 16 + q) * D + d] * sc;
             lt += sl[w * 16 + q] * sc;
         }
-        const size_t idx = (((size_t)b * Hq + hk * n_rep + q) * nsplit + split);
+        const size_t idx = (((size_t)b * Hq + hk * n_rep + q) * nsplit_tot + split_off + split);
         part_o[idx * D + d] = acc;
         if (d == 0) {
             part_ml[idx * 2] = mn;
             part_ml[idx * 2 + 1] = lt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Group decode attention over a SHARED prompt prefix (head_dim 128).  The G completions of one prompt
+// (num_return_sequences, R:grpo_trainer.py:306-313; n samples, R:eval/tts.py:47-123) attend to the same first
+// `P` keys, so those K/V bytes are read once for the whole group instead of G times: the G * n_rep query rows
+// (sequence-major) fill NQB 16-column blocks of the swapped QK^T product.  Keys past the prefix (each row's own
+// generated tokens) are handled by attn_decode_mfma_kernel with kbeg = P; attn_decode_combine_kernel merges both.
+// K/V of the prefix are read from the cache row of the group's first sequence.
+// ------------------------------------------------------------------------------------------------
+template <int NQB>
+__global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                                const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
+                                                                int P, int G, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
+                                                                float scale_log2e, int nsplit_tot) {
+    constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE, QSTRIDE = 272, NQ = NQB * 16;
+    constexpr int Q_BYTES = NQ * QSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // Q rows | 4 x V slice ; reused: so[NQ][128] | sm | sl
+    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b0 = blockIdx.z * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k_lo = k_lo_arr ? k_lo_arr[b0] : 0;
+    const int nq = G * n_rep;
+    char* Qs = smem;
+    char* Vl = smem + Q_BYTES + wave * V_BYTES;
+
+    // ---- Q rows of the group -> LDS (row q = seq * n_rep + r; rows past nq are zero)
+    for (int c = threadIdx.x; c < NQ * 16; c += 256) {
+        const int q = c >> 4, ch = c & 15;
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (q < nq) {
+            const int seq = q / n_rep, r = q - seq * n_rep;
+            v = *reinterpret_cast<const u32x4*>(Q + ((size_t)(b0 + seq) * Hq + hk * n_rep + r) * D + ch * 8);
+        }
+        *reinterpret_cast<u32x4*>(Qs + q * QSTRIDE + ch * 16) = v;
+    }
+    __syncthreads();
+
+    int chunk = (P + nsplit - 1) / nsplit;
+    chunk = (chunk + 4 * KT - 1) / (4 * KT) * (4 * KT);
+    const int per_wave = chunk >> 2;
+    const int kw0 = split * chunk + wave * per_wave;
+    int kw1 = kw0 + per_wave;
+    kw1 = kw1 < P ? kw1 : P;
+    const bf16_t* Kb = Kc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
+    const bf16_t* Vb = Vc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
+
+    float m_run[NQB], l_run[NQB];
+    f32x4 o[NQB][8];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        m_run[qb] = -1e30f;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[qb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int tq = fr >> 2, tp = fr & 3;
+
+    for (int key0 = kw0; key0 < kw1; key0 += KT) {
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            int kr = key0 + kb * 16 + fr;
+            kr = kr < P ? kr : P - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Kb + (size_t)kr * D + ks * 32 + fg * 8);
+        }
+        u32x4 vreg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i * 64 + lane, row = c >> 4, ch = c & 15;
+            int kr = key0 + row;
+            kr = kr < P ? kr : P - 1;
+            vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (size_t)kr * D + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i * 64 + lane, row = c >> 4, ch = c & 15;
+            *reinterpret_cast<u32x4*>(Vl + row * VSTRIDE + ch * 16) = vreg[i];
+        }
+        bool ok[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = key0 + kb * 16 + fg * 4 + r;
+                ok[kb][r] = (j < kw1) && (j >= k_lo);
+            }
+        const char* r0 = Vl + (fg * 4 + tq) * VSTRIDE + tp * 8;
+        const char* r1 = r0 + 16 * VSTRIDE;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            // ---- S^T = K . Q^T for this block of 16 query rows
+            f32x4 sacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qb * 16 + fr) * QSTRIDE + ks * 64 + fg * 16);
+                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][ks], qf, sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][ks], qf, sacc[1], 0, 0, 0);
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = ok[kb][r] ? sacc[kb][r] * scale_log2e : -1e30f;
+                    sacc[kb][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+            bf16x8 pb;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = ok[kb][r] ? __builtin_amdgcn_exp2f(sacc[kb][r] - m_new) : 0.f;
+                    const bf16_t pq = f2bf(p);
+                    psum += bf2f(pq);
+                    pb[kb * 4 + r] = (short)pq;
+                }
+            l_run[qb] = l_run[qb] * alpha + psum;
+            // ---- O^T += V^T . P^T
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + db * 32));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + db * 32));
+                const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                o[qb][db] *= alpha;
+                o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, o[qb][db], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the 4 waves in wave order (deterministic): global max per query row, then scaled accumulation in LDS
+    __syncthreads();                                        // Q rows and V slices are dead
+    float* so = reinterpret_cast<float*>(smem);             // [NQ][128]
+    float* sm = so + NQ * D;                                // [4][NQ]
+    float* sl = sm + 4 * NQ;                                // [NQ]
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+        if (fg == 0) sm[wave * NQ + qb * 16 + fr] = m_run[qb];
+    __syncthreads();
+    float wsc[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int q = qb * 16 + fr;
+        const float mg = fmaxf(fmaxf(sm[q], sm[NQ + q]), fmaxf(sm[2 * NQ + q], sm[3 * NQ + q]));
+        wsc[qb] = __builtin_amdgcn_exp2f(m_run[qb] - mg);
+        float lt = l_run[qb] + __shfl_xor(l_run[qb], 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        l_run[qb] = lt * wsc[qb];
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+                for (int db = 0; db < 8; ++db) {
+                    float* dst = so + ((size_t)(qb * 16 + fr) * D + db * 16 + fg * 4);
+                    f32x4 v = o[qb][db] * wsc[qb];
+                    if (w > 0) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+                if (fg == 0) sl[qb * 16 + fr] = (w > 0 ? sl[qb * 16 + fr] : 0.f) + l_run[qb];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < nq * D; i += 256) {
+        const int q = i / D, d = i % D;
+        const int seq = q / n_rep, r = q - seq * n_rep;
+        const size_t idx = (((size_t)(b0 + seq) * Hq + hk * n_rep + r) * nsplit_tot + split);
+        part_o[idx * D + d] = so[(size_t)q * D + d];
+        if (d == 0) {
+            part_ml[idx * 2] = fmaxf(fmaxf(sm[q], sm[NQ + q]), fmaxf(sm[2 * NQ + q], sm[3 * NQ + q]));
+            part_ml[idx * 2 + 1] = sl[q];
         }
     }
 }
@@ -660,7 +852,7 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
                 O3V_AD(128);
             } else {
                 O3V_KLAUNCH(attn_decode_mfma_kernel, grid, block, 4 * 32 * 288, stream, (const bf16_t*)Q, (const bf16_t*)Kc,
-                            (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2);
+                            (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2, 0, nsplit, 0, 1, 0);
                 O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml,
                             (bf16_t*)out, nsplit);
             }
@@ -668,6 +860,57 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
         default: return O3V_ERR_SHAPE;
     }
 #undef O3V_AD
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
+                                     const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
+                                     int nsplit_prefix, float scale, hipStream_t stream) {
+    if (!Q || !Kc || !Vc || !out || !part_o || !part_ml || B <= 0 || G <= 1 || (B % G) || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) ||
+        prefix_len <= 0 || ctx <= prefix_len || ctx > Tmax || nsplit_prefix == 0)
+        return O3V_ERR_ARG;
+    const int n_rep = Hq / Hkv;
+    if (D != 128 || G * n_rep > 64) return O3V_ERR_SHAPE;
+    if (nsplit_prefix < 0) {
+        // shared-read form: the per-row kernel, with every row of a group reading the prefix from the group's first row
+        const int ns = -nsplit_prefix;
+        if (ns > 64) return O3V_ERR_ARG;
+        O3V_KLAUNCH(attn_decode_mfma_kernel, dim3(ns, Hkv, B), dim3(256), 4 * 32 * 288, stream, (const bf16_t*)Q, (const bf16_t*)Kc,
+                    (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, (long)Tmax * D, (long)Hkv * Tmax * D,
+                    scale * 1.4426950408889634f, 0, ns, 0, G, prefix_len);
+        O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml, (bf16_t*)out, ns);
+        O3V_CHECK_LAUNCH();
+        return O3V_OK;
+    }
+    const int nsplit_own = (ctx - prefix_len + 127) / 128;
+    const int nsplit_tot = nsplit_prefix + nsplit_own;
+    if (nsplit_tot > 64) return O3V_ERR_ARG;
+    const float sl2 = scale * 1.4426950408889634f;
+    const long k_hs = (long)Tmax * D, k_bs = (long)Hkv * Tmax * D;
+    const int nqb = (G * n_rep + 15) / 16;
+    dim3 grid(nsplit_prefix, Hkv, B / G), block(256);
+#define O3V_AG(NQB)                                                                                                         \
+    O3V_KLAUNCH((attn_decode_group_kernel<NQB>), grid, block,                                                                \
+                (size_t)((NQB * 16 * 272 + 4 * 32 * 288) > (NQB * 16 * 128 * 4 + 5 * NQB * 16 * 4)                         \
+                             ? (NQB * 16 * 272 + 4 * 32 * 288)                                                              \
+                             : (NQB * 16 * 128 * 4 + 5 * NQB * 16 * 4)),                                                    \
+                stream, (const bf16_t*)Q, (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, prefix_len, G, Hq,   \
+                Hkv, n_rep, k_hs, k_bs, sl2, nsplit_tot)
+    if (nqb == 1)
+        O3V_AG(1);
+    else if (nqb == 2)
+        O3V_AG(2);
+    else if (nqb == 3)
+        O3V_AG(3);
+    else
+        O3V_AG(4);
+#undef O3V_AG
+    O3V_KLAUNCH(attn_decode_mfma_kernel, dim3(nsplit_own, Hkv, B), block, 4 * 32 * 288, stream, (const bf16_t*)Q,
+                (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2, prefix_len,
+                nsplit_tot, nsplit_prefix, 1, 0);
+    O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml, (bf16_t*)out,
+                nsplit_tot);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

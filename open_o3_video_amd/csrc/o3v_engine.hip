@@ -234,8 +234,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                     TRY(o3v_prefetch(lw.gu_w, (pb - o_bytes) < gu_bytes ? (pb - o_bytes) : gu_bytes, 48, st->part_ml,
                                      st->side_stream));
             }
-            TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
-                                st->Tmax, st->nsplit, scale, s));
+            if (st->group > 1)  // the rows of a group share the prompt K/V: read it once per group
+                TRY(o3v_attn_decode_group(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D, st->S,
+                                          st->S + step + 1, st->Tmax, st->nsplit, scale, s));
+            else
+                TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
+                                    st->Tmax, st->nsplit, scale, s));
             TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H,
                                   O3V_EPI_RESIDUAL, s));
             TRY(o3v_linear_decode(st->x, lw.ln2, d->rms_eps, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,

@@ -62,6 +62,8 @@ class O3VEngine:
         import os
         self.prefetch_bytes = int(float(os.environ.get("O3V_PREFETCH_MB", "0")) * 1e6)
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.prefetch_bytes > 0 else None
+        self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
+        self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
 
     # ------------------------------------------------------------------------------------------ vision
     def _vit_plan(self, grid_thw):
@@ -289,8 +291,23 @@ class O3VEngine:
         rid = torch.tensor(list(row_ids) if row_ids is not None else list(range(B)), dtype=torch.int32, device=self.dev)
         n_rep_total = B * tc.num_attention_heads
         nsplit = max(1, min(64, (Tmax + 127) // 128, max(1, 2048 // max(1, B * tc.num_key_value_heads))))
-        part_o = torch.empty(n_rep_total * nsplit * tc.head_dim, dtype=torch.float32, device=self.dev)
-        part_ml = torch.empty(n_rep_total * nsplit * 2, dtype=torch.float32, device=self.dev)
+        # G completions of a prompt share its K/V: the group kernel reads the prompt keys once per group (head_dim 128,
+        # G * n_rep <= 64 query rows per kv head, prefix splits + own-key splits <= 64)
+        n_rep = tc.num_attention_heads // tc.num_key_value_heads
+        own_splits = (T + 127) // 128
+        group = G if (G > 1 and tc.head_dim == 128 and G * n_rep <= 64 and own_splits <= 32 and self.group_attention) else 0
+        mode = self.group_attention_mode
+        if mode == "auto":
+            # measured, 7B dims, G=8 (tools/measure_configs.py rollout / rollout_eval): at S=4.5k the per-row kernel reading the
+            # group leader's prefix through the shared L2 wins (4.56 vs 4.80 ms/step); at S=10k the one-pass group kernel
+            # does (4.96 vs 5.08); without either 4.73 / 5.42
+            mode = "kernel" if S >= 8192 else "shared_read"
+        if group and mode == "shared_read":
+            nsplit = -nsplit
+        elif group:
+            nsplit = max(1, min(64 - own_splits, (S + 127) // 128))
+        part_o = torch.empty(n_rep_total * 64 * tc.head_dim, dtype=torch.float32, device=self.dev)
+        part_ml = torch.empty(n_rep_total * 64 * 2, dtype=torch.float32, device=self.dev)
         scratch = torch.empty((B, V if do_sample else 256), dtype=torch.float32, device=self.dev)
         xdec = torch.empty((B, H), dtype=torch.bfloat16, device=self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B)
@@ -305,7 +322,7 @@ class O3VEngine:
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
                               sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
                               ws_bytes=nbytes, side_stream=0 if self.side_stream is None else self.side_stream.cuda_stream,
-                              prefetch_bytes=self.prefetch_bytes)
+                              prefetch_bytes=self.prefetch_bytes, group=group)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
         use_eos = len(eos_token_ids) > 0

@@ -59,6 +59,17 @@ def attn_decode(q, kc, vc, k_lo, ctx, nsplit, scale):
     return out
 
 
+def attn_decode_group(q, kc, vc, k_lo, G, prefix_len, ctx, nsplit_prefix, scale):
+    B, Hq, D = q.shape
+    _, Hkv, Tmax, _ = kc.shape
+    out = torch.empty_like(q)
+    po = torch.empty(B * Hq * 64 * D, dtype=torch.float32, device=q.device)
+    pm = torch.empty(B * Hq * 64 * 2, dtype=torch.float32, device=q.device)
+    _lib.call("o3v_attn_decode_group", _p(q), _p(kc), _p(vc), _p(out), _p(po), _p(pm), _p(k_lo), B, G, Hq, Hkv, D, prefix_len, ctx,
+              Tmax, nsplit_prefix, float(scale), _s())
+    return out
+
+
 def gather_rows(src, idx):
     out = torch.empty((idx.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
     _lib.call("o3v_gather_rows", _p(src), _p(idx), _p(out), idx.shape[0], src.shape[1] * src.element_size(), _s())

@@ -405,6 +405,44 @@ def test_attn_decode(dev, B, Hq, Hkv, D, ctx, pads, nsplit):
         close_bf16(out[b], ref, ulps=3, atol=4e-3)
 
 
+@pytest.mark.parametrize("B,G,Hq,Hkv,P,own,pad,nsp", [
+    (8, 8, 28, 4, 1000, 1, 0, 8), (8, 8, 28, 4, 333, 77, 5, 3), (8, 4, 28, 4, 515, 130, 0, 5), (6, 2, 28, 4, 97, 300, 40, 1),
+    (3, 3, 16, 2, 260, 33, 0, 4), (6, 6, 28, 4, 4490, 511, 0, 36), (4, 4, 8, 2, 64, 1, 63, 2),
+    # negative split count: the shared-read form (per-row kernel, prefix read from the group's first row)
+    (8, 8, 28, 4, 1000, 1, 0, -8), (8, 4, 28, 4, 515, 130, 7, -5), (6, 2, 28, 4, 97, 300, 40, -3), (6, 6, 28, 4, 4490, 511, 0, -40)])
+def test_attn_decode_group(dev, B, G, Hq, Hkv, P, own, pad, nsp):
+    """Shared-prefix group decode attention: rows of a group read the prefix K/V of the group's FIRST row only (the other
+    rows' prefix slots are poisoned here), their own keys from their own row; checked against fp32 softmax attention."""
+    from open_o3_video_amd import ops
+    D = 128
+    ctx = P + own
+    Tmax = ctx + 5
+    g = torch.Generator().manual_seed(P + own)
+    q = torch.randn(B, Hq, D, generator=g).to(BF)
+    kp = torch.randn(B // G, Hkv, P, D, generator=g).to(BF)
+    vp = torch.randn(B // G, Hkv, P, D, generator=g).to(BF)
+    k = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    v = torch.randn(B, Hkv, Tmax, D, generator=g).to(BF)
+    k_true, v_true = k.clone(), v.clone()
+    k_true[:, :, :P] = kp.repeat_interleave(G, dim=0)
+    v_true[:, :, :P] = vp.repeat_interleave(G, dim=0)
+    k[:, :, :P] = 100.0                                     # poison: must never be read for non-leader rows
+    v[:, :, :P] = -100.0
+    k[::G, :, :P] = kp
+    v[::G, :, :P] = vp
+    pads = torch.full((B,), pad, dtype=torch.int32)
+    out = ops.attn_decode_group(q.to(dev), k.to(dev), v.to(dev), pads.to(dev), G, P, ctx, nsp, D ** -0.5).cpu()
+    rep = Hq // Hkv
+    for b in range(B):
+        kk = k_true[b, :, pad:ctx].repeat_interleave(rep, dim=0)
+        vv = v_true[b, :, pad:ctx].repeat_interleave(rep, dim=0)
+        ref = _attn_ref(q[b][:, None, :], kk, vv, D ** -0.5)[:, 0]
+        close_bf16(out[b], ref, ulps=3, atol=4e-3)
+    # the ungrouped kernel on the fanned-out cache gives the same answer to within the split-order rounding
+    std = ops.attn_decode(q.to(dev), k_true.to(dev), v_true.to(dev), pads.to(dev), ctx, max(1, min(16, ctx // 128)), D ** -0.5).cpu()
+    close_bf16(out, std, ulps=3, atol=4e-3)
+
+
 def test_patchify_matches_hf_processor(dev, golden_dir):
     """uint8 frames -> pixel rows: bit-exact against Qwen2VLImageProcessor output (golden G3), after the bf16 cast."""
     import ctypes as C

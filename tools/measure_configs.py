@@ -44,6 +44,9 @@ if "rollout" in which:
     for G in ([int(a[1:]) for a in sys.argv[1:] if a.startswith('G')] or (2, 4, 8)):
         run(f"rollout G={G} sampled top_p=0.95 (TRAIN-RES)", 32, 224, 420, 4490, 256, num_return_sequences=G, do_sample=True,
             top_p=0.95, temperature=1.0, seed=1)
+if "rollout_eval" in which:
+    run("rollout G=8 sampled top_p=0.95 (EVAL-RES, S=10218)", 32, 364, 644, 10218, 128, num_return_sequences=8, do_sample=True,
+        top_p=0.95, temperature=1.0, seed=1)
 if "long" in which:
     run("LONG 256x224x224 greedy B=1", 256, 224, 224, 256 * (64 + 15) + 170, 128, repetition_penalty=1.05)
 
