@@ -114,6 +114,7 @@ int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* o
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
  * TF:generation/utils.py:2894-2929, TF:generation/logits_process.py:404-414 */
+#define O3V_SAMPLE_SCRATCH_FLOATS 24576 /* per-row accumulators of o3v_sample_top_p (histograms, slice maxima / masses) */
 int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
                       const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
                       int out_stride, float* scratch /* f32[B*256] */, o3v_stream_t stream);
@@ -121,8 +122,8 @@ int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finishe
  * keyed by (seed, row_id[b], step) so a completion does not depend on which rank/batch slot produced it */
 int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* chosen_logprob,
                      const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, float temperature,
-                     float top_p, uint64_t seed, const int* row_id, int step, int out_stride, float* scratch,
-                     o3v_stream_t stream);
+                     float top_p, uint64_t seed, const int* row_id, int step, int out_stride,
+                     float* scratch /* f32[B * O3V_SAMPLE_SCRATCH_FLOATS], 8-byte aligned */, o3v_stream_t stream);
 int o3v_mark_seen(const int* ids, void* seen, int B, int S, int V, o3v_stream_t stream);
 /* _get_per_token_logps, R:grpo_trainer.py:371-384: out[r] = log_softmax(logits[r])[target[r]] */
 int o3v_logprob_gather(const void* logits, const int* target, float* out, int R, int V, int ldl, o3v_stream_t stream);
@@ -203,7 +204,7 @@ typedef struct {
     const int *k_lo;             /* [B] left-pad counts or NULL */
     const int *row_id;           /* [B] global completion index for the RNG or NULL */
     float *part_o, *part_ml;     /* decode-attention split buffers */
-    float *sample_scratch;       /* f32 [B,vocab] when sampling, f32 [B,256] for greedy */
+    float *sample_scratch;       /* f32 [B, O3V_SAMPLE_SCRATCH_FLOATS] when sampling, f32 [B,256] for greedy */
     void *workspace; size_t ws_bytes;
     o3v_stream_t side_stream;    /* optional: weight prefetch runs here beside the decode attention (NULL = off) */
     size_t prefetch_bytes;       /* bytes of the next projections' weights to pull on-die per layer */

@@ -80,6 +80,8 @@ SIGNATURES = {
 }
 _RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz}
 
+SAMPLE_SCRATCH_FLOATS = 24576   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h
+
 _lib = None
 
 

@@ -1,14 +1,32 @@
-// Rollout sampler: repetition penalty -> temperature -> top-p -> multinomial, one 1024-thread block per
-// sequence, no sort.  Restates TF:generation/logits_process.py:404-414 (penalty), :301-303 (temperature),
+// Rollout sampler: repetition penalty -> temperature -> top-p -> multinomial, 32 blocks per sequence, no sort.  Restates TF:generation/logits_process.py:404-414 (penalty), :301-303 (temperature),
 // :527-539 (top-p: drop the ascending-sorted prefix whose cumulative probability is <= 1-top_p, keep >= 1)
 // and TF:generation/utils.py:2921-2923 (softmax -> multinomial) as used by the GSPO rollout
 // (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313: do_sample, top_p 0.95, temperature 1).
-// The top-p cut is found by a radix select on the probability bit pattern (kept set {p >= tau}); the draw walks the
-// kept mass in index order.  RNG: counter-based (splitmix64 of seed, completion id, step) so a completion is
-// reproducible wherever it is generated.
+//
+// The row (152064 bf16 logits = 300 KB, L2-resident right after the lm_head) is streamed five times with 16-byte
+// loads, eight groups in flight per thread; nothing is written back.  Probability mass is carried as 2^-40 fixed point
+// (e = exp(s - max) <= 1), so every sum -- the normaliser, the radix-select histograms, the draw -- is an integer sum:
+// exact and independent of the order the atomics land in, hence reproducible.
+//   pass A  max of the processed scores
+//   pass B  z = sum e and the level-0 histogram of mass over the top 12 bits of e (values below 2^-24 are lumped)
+//   pass C/D levels 1 and 2 (12 and 7 more bits) of the radix select for the smallest tau with mass{e <= tau} > (1-top_p) z
+//   pass E  kept mass {e >= tau} per thread, block scan, the thread holding the drawn target walks its own elements
+// RNG: counter-based (splitmix64 of seed, completion id, step) so a completion is reproducible wherever it is generated
+// (SURVEY.md section 8e).
 #include "o3v_common.h"
 
 namespace {
+
+constexpr int NT = 256, NBLK = 32;                  // threads per block, blocks per row
+constexpr float FX_SCALE = 1099511627776.0f;        // 2^40
+
+typedef unsigned long long u64;
+
+// per-row workspace (u64 units) inside the caller's scratch: O3V_SAMPLE_SCRATCH_FLOATS floats per row
+constexpr int WS_H0 = 0, WS_H1 = 4096, WS_H2 = 8192, WS_BM = 8320, WS_Z = 8352, WS_PREFIX = 8353, WS_PMAX = 8354;
+constexpr int WS_U64 = 8354 + NBLK / 2;             // pmax: NBLK floats
+constexpr int WS_FLOATS = 24576;
+static_assert(WS_U64 * 2 <= WS_FLOATS, "row workspace");
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -17,193 +35,320 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__device__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
-    return t;
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int d) {
+    const unsigned lo = __shfl_up((unsigned)v, d, 64), hi = __shfl_up((unsigned)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ float block_max(float v, float* red) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float t = -INFINITY;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, red[i]);
+    for (int i = 0; i < NT / 64; ++i) t = fmaxf(t, red[i]);
     return t;
 }
-
-__global__ __launch_bounds__(1024) void sample_top_p_kernel(const bf16_t* __restrict__ logits, uint8_t* __restrict__ seen,
-                                                            int* __restrict__ cur_tok, int* __restrict__ finished,
-                                                            int* __restrict__ out_ids, float* __restrict__ chosen_lp,
-                                                            const int* __restrict__ eos_ids, int n_eos, int pad_id, int V,
-                                                            int ldl, float rep_penalty, float temperature, float top_p,
-                                                            uint64_t seed, const int* __restrict__ row_id, int step,
-                                                            int out_stride, float* __restrict__ scratch) {
-    __shared__ float red[16];
-    __shared__ float csum[1024];
-    __shared__ float hist[4096];
-    __shared__ int s_pick;
-    __shared__ float s_below;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* lr = logits + (size_t)b * ldl;
-    uint8_t* sr = seen + (size_t)b * V;
-    float* pr = scratch + (size_t)b * V;
-
-    // 1. processed scores, max
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += 1024) {
-        float s = bf2f(lr[i]);
-        if (rep_penalty != 1.0f && sr[i]) s = (s < 0.f) ? s * rep_penalty : s / rep_penalty;
-        s = s / temperature;
-        pr[i] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = block_max(mx, red);
-    // 2. probabilities
-    float z = 0.f;
-    for (int i = tid; i < V; i += 1024) {
-        const float e = expf(pr[i] - mx);
-        pr[i] = e;
-        z += e;
-    }
-    z = block_sum(z, red);
-    const float invz = 1.0f / z;
-    // 3. top-p threshold by a 3-level radix select on the bit pattern of p (positive floats order like their bits):
-    //    smallest tau with M(tau) = sum_{p <= tau} p > 1 - top_p; the kept set is {p >= tau} (TF keeps the complement of
-    //    the ascending prefix with cumulative probability <= 1 - top_p).  Each level histograms probability MASS over
-    //    12 / 12 / 7 bits of the elements that match the prefix found so far: 3 passes instead of a 30-pass bisection.
-    float lo = 0.f;  // kept: p > lo  (lo = largest representable value below tau)
-    if (top_p < 1.0f) {
-        const float cut = 1.0f - top_p;
-        unsigned prefix = 0;       // bits of tau decided so far (high bits)
-        float below = 0.f;         // mass of all p whose high bits are < prefix
-        const int shifts[3] = {19, 7, 0};
-        const int widths[3] = {12, 12, 7};
-        for (int lvl = 0; lvl < 3; ++lvl) {
-            const int sh = shifts[lvl], nb = 1 << widths[lvl];
-            for (int i = tid; i < nb; i += 1024) hist[i] = 0.f;
-            __syncthreads();
-            const unsigned hi_mask = (lvl == 0) ? 0u : (0xffffffffu << (sh + widths[lvl]));
-            for (int i = tid; i < V; i += 1024) {
-                const float p = pr[i] * invz;
-                const unsigned bits = __float_as_uint(p);
-                if ((bits & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(bits >> sh) & (nb - 1)], p);
-            }
-            __syncthreads();
-            // exclusive scan of the bins in ascending order; every thread owns nb/1024 (>= 1) consecutive bins
-            const int per = nb >= 1024 ? nb / 1024 : 1;
-            float mine = 0.f;
-            if (tid * per < nb)
-                for (int k = 0; k < per; ++k) mine += hist[tid * per + k];
-            float incl = mine;  // inclusive scan across the block
+__device__ u64 block_sum_u64(u64 v, u64* red) {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const float t = __shfl_up(incl, o, 64);
-                if ((tid & 63) >= o) incl += t;
-            }
-            if ((tid & 63) == 63) red[tid >> 6] = incl;
-            __syncthreads();
-            float wave_off = 0.f;
-            for (int w = 0; w < (tid >> 6); ++w) wave_off += red[w];
-            const float before = below + wave_off + incl - mine;
-            if (tid == 0) s_pick = -1;
-            __syncthreads();
-            if (tid * per < nb && mine > 0.f && before <= cut && before + mine > cut) {
-                float run = before;
-                for (int k = 0; k < per; ++k) {
-                    const float h = hist[tid * per + k];
-                    if (h > 0.f && run + h > cut) {
-                        s_pick = tid * per + k;
-                        s_below = run;
-                        break;
-                    }
-                    run += h;
-                }
-            }
-            __syncthreads();
-            if (s_pick < 0) {  // rounding left the crossing undetected: take the highest non-empty bin
-                if (tid == 0) {
-                    float run = below;
-                    int lastb = 0;
-                    float lastrun = below;
-                    for (int k = 0; k < nb; ++k)
-                        if (hist[k] > 0.f) {
-                            lastb = k;
-                            lastrun = run;
-                            run += hist[k];
-                        }
-                    s_pick = lastb;
-                    s_below = lastrun;
-                }
-                __syncthreads();
-            }
-            prefix |= ((unsigned)s_pick) << sh;
-            below = s_below;
-            __syncthreads();
-        }
-        // tau = prefix (all 31 value bits decided); keep p >= tau  <=>  p > tau_minus
-        lo = __uint_as_float(prefix > 0 ? prefix - 1 : 0u);
-    }
-    // 4. kept mass per contiguous index chunk, then the draw
-    const int chunk = (V + 1023) / 1024;
-    const int i0 = tid * chunk, i1 = (i0 + chunk < V) ? i0 + chunk : V;
-    float mine = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float p = pr[i] * invz;
-        mine += (p > lo) ? p : 0.f;
-    }
-    csum[tid] = mine;
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
     __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < 1024; ++i) tot += csum[i];
-        const uint64_t rid = row_id ? (uint64_t)row_id[b] : (uint64_t)b;
-        const uint64_t r = splitmix64(splitmix64(seed ^ (rid * 0xD1B54A32D192ED03ull)) + (uint64_t)step);
-        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
-        float target = u * tot;
-        int t = 0;
-        float run = 0.f;
-        for (; t < 1023; ++t) {
-            if (run + csum[t] > target) break;
-            run += csum[t];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 t = 0;
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+// exclusive prefix of `v` over the block in thread order; *total = block sum
+__device__ u64 block_scan_excl_u64(u64 v, u64* red, u64* total) {
+    u64 incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = shfl_up_u64(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u64 off = 0, tot = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) off += red[w];
+        tot += red[w];
+    }
+    *total = tot;
+    return off + incl - v;
+}
+
+struct Row {
+    const bf16_t* lr;
+    const uint8_t* sr;
+    int V;
+    bool vec;
+    float rep, temp;
+};
+
+__device__ __forceinline__ Row make_row(const bf16_t* logits, const uint8_t* seen, int b, int V, int ldl, float rep, float temp) {
+    Row r;
+    r.lr = logits + (size_t)b * ldl;
+    r.sr = seen + (size_t)b * V;
+    r.V = V;
+    r.vec = ((V & 7) == 0) && ((ldl & 7) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) &&
+            ((reinterpret_cast<uintptr_t>(seen) & 7) == 0);
+    r.rep = rep;
+    r.temp = temp;
+    return r;
+}
+
+// processed scores of elements 8g..8g+7 (TF:404-414 penalty, :301-303 temperature); -inf past the vocabulary
+__device__ __forceinline__ void load_group(const Row& r, int g, float s[8]) {
+    const int base = g * 8;
+    if (r.vec && base + 8 <= r.V) {
+        const u32x4 lv = *reinterpret_cast<const u32x4*>(r.lr + base);
+        const uint2 sv = *reinterpret_cast<const uint2*>(r.sr + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = bf2f((bf16_t)((lv[k >> 1] >> (16 * (k & 1))) & 0xffffu));
+            const unsigned sb = ((k < 4 ? sv.x : sv.y) >> (8 * (k & 3))) & 0xffu;
+            if (r.rep != 1.0f && sb) x = (x < 0.f) ? x * r.rep : x / r.rep;
+            s[k] = x / r.temp;
         }
-        // walk thread t's chunk
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k;
+            float x = -INFINITY;
+            if (i < r.V) {
+                x = bf2f(r.lr[i]);
+                if (r.rep != 1.0f && r.sr[i]) x = (x < 0.f) ? x * r.rep : x / r.rep;
+                x = x / r.temp;
+            }
+            s[k] = x;
+        }
+    }
+}
+
+// Visits the elements of block `blk`'s slice of the row: thread t owns groups g0+t, g0+t+NT, ...
+template <typename F>
+__device__ __forceinline__ void for_each_score(const Row& r, int blk, F&& f) {
+    const int NG = (r.V + 7) / 8, per_blk = (NG + NBLK - 1) / NBLK;
+    const int g0 = blk * per_blk, g1 = (g0 + per_blk < NG) ? g0 + per_blk : NG;
+    for (int g = g0 + threadIdx.x; g < g1; g += NT) {
+        float s[8];
+        load_group(r, g, s);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f(g * 8 + k, s[k]);
+    }
+}
+
+__device__ __forceinline__ u64 to_fx(float e) { return (u64)(e * FX_SCALE); }
+
+__device__ __forceinline__ float row_max(const u64* ws) {
+    const float* pm = reinterpret_cast<const float*>(ws + WS_PMAX);
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) m = fmaxf(m, pm[i]);
+    return m;
+}
+
+// Bin of `hist[0..nb)` in which the running mass (starting at *below) first exceeds `cut`; *below becomes the mass
+// before that bin.  Every thread of the block returns the same value.
+__device__ int pick_bin(const u64* __restrict__ hist, int nb, u64 cut, u64* below, u64* red, int* s_pick, u64* s_below) {
+    const int per = (nb + NT - 1) / NT, tid = threadIdx.x;
+    const int k0 = tid * per, k1 = (k0 + per < nb) ? k0 + per : nb;
+    u64 mine = 0;
+    for (int k = k0; k < k1; ++k) mine += hist[k];
+    u64 tot;
+    const u64 before = *below + block_scan_excl_u64(mine, red, &tot);
+    if (tid == 0) *s_pick = -1;
+    __syncthreads();
+    if (mine > 0 && before <= cut && before + mine > cut) {
+        u64 run = before;
+        for (int k = k0; k < k1; ++k) {
+            const u64 h = hist[k];
+            if (h > 0 && run + h > cut) {
+                *s_pick = k;
+                *s_below = run;
+                break;
+            }
+            run += h;
+        }
+    }
+    __syncthreads();
+    if (*s_pick < 0) {  // cut >= all the mass at this level (top_p ~ 0): take the highest non-empty bin
+        if (tid == 0) {
+            u64 run = *below, lastrun = *below;
+            int lastb = 0;
+            for (int k = 0; k < nb; ++k)
+                if (hist[k] > 0) {
+                    lastb = k;
+                    lastrun = run;
+                    run += hist[k];
+                }
+            *s_pick = lastb;
+            *s_below = lastrun;
+        }
+        __syncthreads();
+    }
+    const int pick = *s_pick;
+    *below = *s_below;
+    __syncthreads();
+    return pick;
+}
+
+// K1: slice maxima of the processed scores; clears the row's accumulators for the kernels that follow
+__global__ __launch_bounds__(NT) void sample_max_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ seen,
+                                                        u64* __restrict__ wsp, int V, int ldl, float rep, float temp) {
+    __shared__ float redf[NT / 64];
+    const int blk = blockIdx.x, b = blockIdx.y;
+    u64* ws = wsp + (size_t)b * (WS_FLOATS / 2);
+    const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
+    for (int i = blk * NT + threadIdx.x; i < WS_PMAX; i += NBLK * NT) ws[i] = 0;
+    float mx = -INFINITY;
+    for_each_score(r, blk, [&](int, float s) { mx = fmaxf(mx, s); });
+    mx = block_max(mx, redf);
+    if (threadIdx.x == 0) reinterpret_cast<float*>(ws + WS_PMAX)[blk] = mx;
+}
+
+// K2..K4 (LVL 0,1,2): mass histogram over 12 / 12 / 7 bits of e = exp(s - max) for the elements that match the bits
+// decided by the earlier levels.  Radix select of the smallest tau with mass{e <= tau} > (1 - top_p) z: the kept set
+// is {e >= tau} (TF keeps the complement of the ascending prefix with cumulative probability <= 1 - top_p).
+template <int LVL>
+__global__ __launch_bounds__(NT) void sample_hist_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ seen,
+                                                         u64* __restrict__ wsp, int V, int ldl, float rep, float temp,
+                                                         float top_p) {
+    constexpr int SH = LVL == 0 ? 19 : (LVL == 1 ? 7 : 0), NB = LVL == 2 ? 128 : 4096;
+    __shared__ u64 hist[NB];
+    __shared__ u64 red[NT / 64];
+    __shared__ int s_pick;
+    __shared__ u64 s_below;
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    u64* ws = wsp + (size_t)b * (WS_FLOATS / 2);
+    const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
+    const float mx = row_max(ws);
+    for (int i = tid; i < NB; i += NT) hist[i] = 0;
+    unsigned prefix = 0, hi_mask = 0;
+    if (LVL > 0) {
+        const u64 cut = (u64)((double)(1.0f - top_p) * (double)ws[WS_Z]);
+        u64 below = 0;
+        prefix = (unsigned)pick_bin(ws + WS_H0, 4096, cut, &below, red, &s_pick, &s_below) << 19;
+        hi_mask = 0xffffffffu << 19;
+        if (LVL > 1) {
+            prefix |= (unsigned)pick_bin(ws + WS_H1, 4096, cut, &below, red, &s_pick, &s_below) << 7;
+            hi_mask = 0xffffffffu << 7;
+        }
+    }
+    __syncthreads();
+    u64 zsum = 0;
+    for_each_score(r, blk, [&](int, float s) {
+        const float e = expf(s - mx);
+        const u64 fx = to_fx(e);
+        const unsigned bits = __float_as_uint(e);
+        if (LVL == 0) zsum += fx;
+        if (fx && (bits & hi_mask) == prefix) atomicAdd(&hist[(bits >> SH) & (NB - 1)], fx);
+    });
+    if (LVL == 0) {
+        zsum = block_sum_u64(zsum, red);
+        if (tid == 0) atomicAdd(ws + WS_Z, zsum);
+    }
+    __syncthreads();
+    u64* gh = ws + (LVL == 0 ? WS_H0 : (LVL == 1 ? WS_H1 : WS_H2));
+    for (int i = tid; i < NB; i += NT)
+        if (hist[i]) atomicAdd(gh + i, hist[i]);
+}
+
+// K5: kept mass {bits(e) >= tau} of every slice; publishes tau (all blocks of a row compute the same value)
+__global__ __launch_bounds__(NT) void sample_mass_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ seen,
+                                                         u64* __restrict__ wsp, int V, int ldl, float rep, float temp,
+                                                         float top_p) {
+    __shared__ u64 red[NT / 64];
+    __shared__ int s_pick;
+    __shared__ u64 s_below;
+    const int blk = blockIdx.x, b = blockIdx.y;
+    u64* ws = wsp + (size_t)b * (WS_FLOATS / 2);
+    const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
+    const float mx = row_max(ws);
+    unsigned prefix = 0;
+    if (top_p < 1.0f) {
+        const u64 cut = (u64)((double)(1.0f - top_p) * (double)ws[WS_Z]);
+        u64 below = 0;
+        prefix = (unsigned)pick_bin(ws + WS_H0, 4096, cut, &below, red, &s_pick, &s_below) << 19;
+        prefix |= (unsigned)pick_bin(ws + WS_H1, 4096, cut, &below, red, &s_pick, &s_below) << 7;
+        prefix |= (unsigned)pick_bin(ws + WS_H2, 128, cut, &below, red, &s_pick, &s_below);
+    }
+    u64 mine = 0;
+    for_each_score(r, blk, [&](int, float s) {
+        const float e = expf(s - mx);
+        if (__float_as_uint(e) >= prefix) mine += to_fx(e);
+    });
+    mine = block_sum_u64(mine, red);
+    if (threadIdx.x == 0) {
+        ws[WS_BM + blk] = mine;
+        ws[WS_PREFIX] = prefix;
+    }
+}
+
+// K6: the draw.  Elements are ordered by slice, then by owning thread, then by that thread's visiting order; the block
+// and then the thread whose mass range holds the target walk to the token.
+__global__ __launch_bounds__(NT) void sample_draw_kernel(const bf16_t* __restrict__ logits, uint8_t* __restrict__ seen,
+                                                         const u64* __restrict__ wsp, int* __restrict__ cur_tok,
+                                                         int* __restrict__ finished, int* __restrict__ out_ids,
+                                                         float* __restrict__ chosen_lp, const int* __restrict__ eos_ids,
+                                                         int n_eos, int pad_id, int V, int ldl, float rep, float temp,
+                                                         uint64_t seed, const int* __restrict__ row_id, int step,
+                                                         int out_stride) {
+    __shared__ u64 red[NT / 64];
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const u64* ws = wsp + (size_t)b * (WS_FLOATS / 2);
+    u64 tot = 0, blk_before = 0;
+    for (int i = 0; i < NBLK; ++i) {
+        if (i < blk) blk_before += ws[WS_BM + i];
+        tot += ws[WS_BM + i];
+    }
+    const uint64_t rid = row_id ? (uint64_t)row_id[b] : (uint64_t)b;
+    const uint64_t rnd = splitmix64(splitmix64(seed ^ (rid * 0xD1B54A32D192ED03ull)) + (uint64_t)step);
+    const double u = (double)(rnd >> 40) * (1.0 / 16777216.0);
+    u64 target = (u64)(u * (double)tot);
+    if (tot > 0 && target >= tot) target = tot - 1;
+    const u64 blk_mass = ws[WS_BM + blk];
+    if (!(blk_mass > 0 && blk_before <= target && target < blk_before + blk_mass)) return;  // block-uniform
+    const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
+    const float mx = row_max(ws);
+    const unsigned prefix = (unsigned)ws[WS_PREFIX];
+    u64 mine = 0;
+    for_each_score(r, blk, [&](int, float s) {
+        const float e = expf(s - mx);
+        if (__float_as_uint(e) >= prefix) mine += to_fx(e);
+    });
+    u64 btot;
+    const u64 before = blk_before + block_scan_excl_u64(mine, red, &btot);
+    if (mine > 0 && before <= target && target < before + mine) {
+        u64 run = before;
         int pick = -1;
-        const int a0 = t * chunk, a1 = (a0 + chunk < V) ? a0 + chunk : V;
-        int last_kept = -1;
-        for (int i = a0; i < a1; ++i) {
-            const float p = pr[i] * invz;
-            if (p > lo) {
-                last_kept = i;
-                run += p;
+        float e_pick = 0.f;
+        for_each_score(r, blk, [&](int i, float s) {
+            if (pick >= 0) return;
+            const float e = expf(s - mx);
+            if (__float_as_uint(e) >= prefix) {
+                run += to_fx(e);
                 if (run > target) {
                     pick = i;
-                    break;
+                    e_pick = e;
                 }
             }
-        }
-        if (pick < 0) pick = last_kept;
-        if (pick < 0) {  // numerical corner: fall back to the arg-max (always kept)
-            float best = -1.f;
-            for (int i = 0; i < V; ++i)
-                if (pr[i] > best) {
-                    best = pr[i];
-                    pick = i;
-                }
-        }
-        int tok = finished[b] ? pad_id : pick;
-        if (!finished[b])
+        });
+        const bool fin = finished[b] != 0;
+        const int tok = fin ? pad_id : pick;
+        if (!fin)
             for (int k = 0; k < n_eos; ++k)
                 if (tok == eos_ids[k]) finished[b] = 1;
-        if (tok >= 0 && tok < V) sr[tok] = 1;
+        if (tok >= 0 && tok < V) seen[(size_t)b * V + tok] = 1;
         cur_tok[b] = tok;
         out_ids[(size_t)b * out_stride + step] = tok;
-        if (chosen_lp) chosen_lp[(size_t)b * out_stride + step] = logf(pr[pick] * invz);
-        s_pick = pick;
+        if (chosen_lp) chosen_lp[(size_t)b * out_stride + step] = logf(e_pick / ((float)ws[WS_Z] * (1.0f / FX_SCALE)));
     }
 }
 
@@ -214,12 +359,22 @@ extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, in
                                 float rep_penalty, float temperature, float top_p, uint64_t seed, const int* row_id, int step,
                                 int out_stride, float* scratch, hipStream_t stream) {
     if (!logits || !seen || !cur_tok || !finished || !out_ids || !scratch || B < 0 || V <= 0 || step < 0 ||
-        step >= out_stride || !(temperature > 0.f) || !(top_p > 0.f))
+        step >= out_stride || !(temperature > 0.f) || !(top_p > 0.f) || (reinterpret_cast<uintptr_t>(scratch) & 7))
         return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
-    O3V_KLAUNCH(sample_top_p_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)logits, (uint8_t*)seen, cur_tok,
-                       finished, out_ids, chosen_logprob, eos_ids, n_eos, pad_id, V, ldl, rep_penalty, temperature,
-                       top_p, seed, row_id, step, out_stride, scratch);
+    const bf16_t* lg = (const bf16_t*)logits;
+    uint8_t* sn = (uint8_t*)seen;
+    u64* ws = (u64*)scratch;
+    const dim3 grid(NBLK, B), block(NT);
+    O3V_KLAUNCH(sample_max_kernel, grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature);
+    O3V_KLAUNCH((sample_hist_kernel<0>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
+    if (top_p < 1.0f) {
+        O3V_KLAUNCH((sample_hist_kernel<1>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
+        O3V_KLAUNCH((sample_hist_kernel<2>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
+    }
+    O3V_KLAUNCH(sample_mass_kernel, grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
+    O3V_KLAUNCH(sample_draw_kernel, grid, block, 0, stream, lg, sn, ws, cur_tok, finished, out_ids, chosen_logprob, eos_ids, n_eos,
+                pad_id, V, ldl, rep_penalty, temperature, seed, row_id, step, out_stride);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

@@ -308,7 +308,7 @@ class O3VEngine:
             nsplit = max(1, min(64 - own_splits, (S + 127) // 128))
         part_o = torch.empty(n_rep_total * 64 * tc.head_dim, dtype=torch.float32, device=self.dev)
         part_ml = torch.empty(n_rep_total * 64 * 2, dtype=torch.float32, device=self.dev)
-        scratch = torch.empty((B, V if do_sample else 256), dtype=torch.float32, device=self.dev)
+        scratch = torch.empty((B, _lib.SAMPLE_SCRATCH_FLOATS if do_sample else 256), dtype=torch.float32, device=self.dev)
         xdec = torch.empty((B, H), dtype=torch.bfloat16, device=self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)

@@ -546,7 +546,7 @@ def test_sample_top_p_support_and_frequencies(dev):
         cur = torch.zeros(B, dtype=torch.int32, device=dev)
         fin = torch.zeros(B, dtype=torch.int32, device=dev)
         eos = torch.tensor([V + 1], dtype=torch.int32, device=dev)
-        scratch = torch.empty(B, V, device=dev)
+        scratch = torch.empty(B, _lib.SAMPLE_SCRATCH_FLOATS, device=dev)
         rid = torch.arange(B, dtype=torch.int32, device=dev)
         for step in range(N):
             _lib.call("o3v_sample_top_p", P(ld), P(seen), P(cur), P(fin), P(out), P(lp), P(eos), 1, 0, B, V, V, 1.0, temp,
@@ -561,3 +561,52 @@ def test_sample_top_p_support_and_frequencies(dev):
         _lib.call("o3v_sample_top_p", P(ld), P(seen), P(cur), P(fin), P(out2), P(lp), P(eos), 1, 0, B, V, V, 1.0, temp,
                   top_p, 1234, P(rid), 5, N, P(scratch), st)
         assert torch.equal(out2[:, 5], out[:, 5])
+
+
+@pytest.mark.parametrize("top_p,temp,rep", [(0.95, 1.0, 1.0), (0.9, 0.8, 1.1), (0.9999, 1.0, 1.05), (1.0, 1.3, 1.0), (0.05, 1.0, 1.0)])
+def test_sample_top_p_full_vocab(dev, top_p, temp, rep):
+    """7B vocabulary (152064): every draw lies in the oracle's top-p set (TF TopPLogitsWarper after penalty and
+    temperature), the reported log-prob is the softmax log-prob of the processed scores, draws are reproducible, rows with
+    different completion ids differ.  top_p=0.9999 puts the threshold deep in the tail; top_p=0.05 keeps only the head."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from oracle import model_ref
+    V, B, N = 152064, 4, 48
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(V, generator=g) * 2.5
+    base[torch.randint(0, V, (12,), generator=g)] += 9.0
+    logits = base.to(BF)[None].repeat(B, 1).contiguous()
+    seen0 = torch.zeros(B, V, dtype=torch.uint8)
+    seen0[:, torch.randint(0, V, (500,), generator=g)] = 1
+    sc = logits[:1].float().clone()
+    if rep != 1.0:
+        m = seen0[:1].bool()
+        sc = torch.where(m, torch.where(sc < 0, sc * rep, sc / rep), sc)       # TF:logits_process.py:404-414
+    sc = model_ref.temperature_warp(sc, temp)
+    kept = torch.isfinite(model_ref.top_p_warp(sc, top_p)[0]) if top_p < 1 else torch.ones(V, dtype=torch.bool)
+    lsm = torch.log_softmax(sc[0], dim=-1)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ld = logits.to(dev)
+    eos = torch.tensor([V + 1], dtype=torch.int32, device=dev)
+    rid = torch.tensor([0, 1, 2, 0], dtype=torch.int32, device=dev)           # rows 0 and 3 are the same completion
+    scratch = torch.empty(B, _lib.SAMPLE_SCRATCH_FLOATS, device=dev)
+    outs = []
+    for rep_run in range(2):
+        out = torch.zeros(B, N, dtype=torch.int32, device=dev)
+        lp = torch.zeros(B, N, device=dev)
+        cur = torch.zeros(B, dtype=torch.int32, device=dev)
+        fin = torch.zeros(B, dtype=torch.int32, device=dev)
+        for step in range(N):
+            seen = seen0.to(dev)                                                # same processed scores at every step
+            _lib.call("o3v_sample_top_p", P(ld), P(seen), P(cur), P(fin), P(out), P(lp), P(eos), 1, 0, B, V, V, rep, temp,
+                      top_p, 77, P(rid), step, N, P(scratch), st)
+            assert bool(seen.cpu()[0, out[0, step].item()] == 1)               # the drawn token is marked seen
+        outs.append((out.cpu().long(), lp.cpu()))
+    o, lp = outs[0]
+    assert torch.equal(o, outs[1][0])
+    assert torch.equal(o[0], o[3]) and not torch.equal(o[0], o[1])
+    assert kept[o.view(-1)].all(), "sampled a token outside the top-p set"
+    np.testing.assert_allclose(lp.view(-1).numpy(), lsm[o.view(-1)].numpy(), rtol=0, atol=2e-4)
+    if top_p >= 0.9:
+        assert len(set(o.view(-1).tolist())) > 3
