@@ -62,6 +62,11 @@ int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, o3
 int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
                  const float* std3, o3v_stream_t stream);
 
+/* crop_box of the test-time-scaling loop, R:eval/tts.py:54-75: boxes int32 [n][5] = {frame, x1, y1, x2, y2} (clipped,
+ * non-empty) of uint8 frames [T,3,H,W] -> uint8 [n,3,H,W], cv2.resize(float32 crop, (W,H), INTER_LINEAR).astype(uint8) */
+int o3v_crop_resize_bilinear(const void* frames, const int* boxes, void* out, int n, int T, int H, int W,
+                             o3v_stream_t stream);
+
 /* Cache prefetch hint: stream `bytes` at `ptr` through `blocks` workgroups (result discarded) so the next reader finds
  * them in L2 / Infinity Cache; meant for a side stream beside a latency-bound kernel. */
 int o3v_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, o3v_stream_t stream);

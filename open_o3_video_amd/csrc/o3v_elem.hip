@@ -402,6 +402,63 @@ extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Test-time-scaling crops (R:eval/tts.py:54-75 crop_box): box [x1,x2) x [y1,y2) of frame f, resized back to the
+// full frame size W x H with OpenCV's INTER_LINEAR on float32 (pixel centres: src = (dst + 0.5) * scale - 0.5,
+// edge replicate, horizontal pass then vertical pass, each a two-term float sum) and truncated to uint8.
+// The frames are already resident on the device for the ViT; nothing goes back to the host.
+// boxes: int32 [n][5] = {frame, x1, y1, x2, y2}, clipped to the frame, x2 > x1, y2 > y1.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_coeff(int d, double scale, int ssize, int& s0, int& s1, float& a0, float& a1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) {
+        f = 0.f;
+        si = 0;
+    }
+    if (si >= ssize - 1) {
+        f = 0.f;
+        si = ssize - 1;
+    }
+    s0 = si;
+    s1 = si + 1 < ssize ? si + 1 : si;
+    a0 = 1.f - f;
+    a1 = f;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_bilinear_kernel(const uint8_t* __restrict__ frames,
+                                                                   const int* __restrict__ boxes, uint8_t* __restrict__ out,
+                                                                   int T, int H, int W) {
+    const int n = blockIdx.z, ch = blockIdx.y;
+    const int f = boxes[n * 5], x1 = boxes[n * 5 + 1], y1 = boxes[n * 5 + 2], x2 = boxes[n * 5 + 3], y2 = boxes[n * 5 + 4];
+    const int cw = x2 - x1, chh = y2 - y1;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W || f < 0 || f >= T || cw <= 0 || chh <= 0) return;
+    const int dy = p / W, dx = p - dy * W;
+    const double sx = (double)cw / (double)W, sy = (double)chh / (double)H;
+    int xa, xb, ya, yb;
+    float ax0, ax1, by0, by1;
+    linear_coeff(dx, sx, cw, xa, xb, ax0, ax1);
+    linear_coeff(dy, sy, chh, ya, yb, by0, by1);
+    const uint8_t* src = frames + ((size_t)f * 3 + ch) * H * W + (size_t)y1 * W + x1;
+    const float r0 = __fadd_rn(__fmul_rn((float)src[(size_t)ya * W + xa], ax0), __fmul_rn((float)src[(size_t)ya * W + xb], ax1));
+    const float r1 = __fadd_rn(__fmul_rn((float)src[(size_t)yb * W + xa], ax0), __fmul_rn((float)src[(size_t)yb * W + xb], ax1));
+    const float v = __fadd_rn(__fmul_rn(r0, by0), __fmul_rn(r1, by1));
+    out[((size_t)n * 3 + ch) * H * W + p] = (uint8_t)(int)v;  // numpy astype(uint8) of a value in [0, 255]: truncation
+}
+
+extern "C" int o3v_crop_resize_bilinear(const void* frames, const int* boxes, void* out, int n, int T, int H, int W,
+                                        hipStream_t stream) {
+    if (!frames || !boxes || !out || n < 0 || T <= 0 || H <= 0 || W <= 0) return O3V_ERR_ARG;
+    if (n == 0) return O3V_OK;
+    if (n > 65535) return O3V_ERR_SHAPE;
+    O3V_KLAUNCH(crop_resize_bilinear_kernel, dim3((H * W + 255) / 256, 3, n), dim3(256), 0, stream, (const uint8_t*)frames, boxes,
+                (uint8_t*)out, T, H, W);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Greedy sampler (TF:generation/utils.py:2894-2929 + logits_process.py:404-414): fp32 view of the bf16
 // last-token logits, repetition penalty over every id seen so far (prompt + generated; `seen` is a
 // byte map [B,V]), argmax with lowest-index tie break, pad after EOS, margin = top1 - top2.

@@ -583,6 +583,49 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     int s_end = s_begin + per;
     s_end = s_end < nks ? s_end : nks;
 
+    // ---- weight stream, double buffered: two trips of U k-steps (UT KiB each) are in flight per wave, and the first one
+    // is issued BEFORE the RMSNorm prologue so the HBM latency of the first weights hides the norm
+    f32x4 acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool has_x = fr < M;
+    constexpr int U = UT / RB;
+    bf16x8 wf0[U][RB], wf1[U][RB], xf0[U], xf1[U];
+    auto load_w = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U], int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sidx = s0 + u;
+            if (sidx < s_end) {  // wave-uniform
+                const int kk = sidx * 32;
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+                    wf[u][b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow[b] + (PACKED ? (size_t)sidx * 512 : (size_t)kk)));
+                if (!NORM)
+                    xf[u] = has_x ? *reinterpret_cast<const bf16x8*>(X + (size_t)fr * ldx + kk + fg * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int b = 0; b < RB; ++b) wf[u][b] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (!NORM) xf[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    auto compute = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U], int s0) {
+        if (NORM) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sidx = s0 + u;
+                const int kk = (sidx < s_end ? sidx : s_begin) * 32;  // past the end the weights are zero: any finite x will do
+                xf[u] = has_x ? *reinterpret_cast<const bf16x8*>(smem + (size_t)fr * xstride + (size_t)(kk + fg * 8) * 2)
+                              : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][b], xf[u], acc[b], 0, 0, 0);
+    };
+    load_w(wf0, xf0, s_begin);
+
     if (NORM) {
         // RMSNorm of the M rows into LDS, one wave per row (rows wave, wave+4, ...): wave-level reduction only, a single
         // block barrier at the end.  Row chunks stay in registers between the two passes when K <= 8 * 512.
@@ -633,33 +676,11 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         __syncthreads();
     }
 
-    f32x4 acc[RB];
-#pragma unroll
-    for (int b = 0; b < RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool has_x = fr < M;
-    constexpr int U = UT / RB;  // UT KiB of weight loads in flight per wave and trip
-    for (int s0 = s_begin; s0 < s_end; s0 += U) {
-        bf16x8 wf[U][RB], xf[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int sidx = s0 + u;
-            const int sld = sidx < s_end ? sidx : s_begin;
-            const int kk = sld * 32;
-#pragma unroll
-            for (int b = 0; b < RB; ++b) {
-                wf[u][b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow[b] + (PACKED ? (size_t)sld * 512 : (size_t)kk)));
-                if (sidx >= s_end) wf[u][b] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-            if (has_x)
-                xf[u] = NORM ? *reinterpret_cast<const bf16x8*>(smem + (size_t)fr * xstride + (size_t)(kk + fg * 8) * 2)
-                             : *reinterpret_cast<const bf16x8*>(X + (size_t)fr * ldx + kk + fg * 8);
-            else
-                xf[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int b = 0; b < RB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][b], xf[u], acc[b], 0, 0, 0);
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+        load_w(wf1, xf1, s0 + U);
+        compute(wf0, xf0, s0);
+        load_w(wf0, xf0, s0 + 2 * U);
+        compute(wf1, xf1, s0 + U);
     }
     if (KS > 1) {
         f32x4* part = reinterpret_cast<f32x4*>(smem + norm_bytes);
@@ -852,6 +873,11 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     }
     if (g_mt_ut == 4) {
         O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 4>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
+                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+        return O3V_OK;
+    }
+    if (g_mt_ut == 8) {
+        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 8>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
                     a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
         return O3V_OK;
     }
