@@ -49,6 +49,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 #define O3V_ERR_ARG (-1)
 #define O3V_ERR_SHAPE (-2)
 #define O3V_ERR_LAUNCH (-3)
+#define O3V_ERR_WORKSPACE (-4)
 
 // hipGetLastError() reports the last error of ANY earlier runtime call of this host thread (torch's own included),
 // so clear it right before our launch and read it right after.

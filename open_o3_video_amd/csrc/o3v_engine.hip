@@ -26,10 +26,25 @@ struct Carver {
     }
 };
 
+constexpr int SPLITK_MAX_ROWS = 128;   // one row tile: the GEMM grid is N/128 blocks, far fewer than the 256 CUs
+constexpr int SPLITK_MAX_N = 8192;
+
 // nn.Linear for any row count: MFMA GEMM above 8 rows, weight-streaming GEMV (in groups of 8 rows) otherwise.
+// splitk_ws (optional, SPLITK floats): lets a 9..128-row GEMM with few output tiles split K over more blocks.
 int linear(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
-           int ldo, int ldr, int epi, o3v_stream_t s) {
-    if (M > 8) return o3v_gemm_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
+           int ldo, int ldr, int epi, o3v_stream_t s, float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+    if (M > 8) {
+        const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        if (splitk_ws && M <= SPLITK_MAX_ROWS && N <= SPLITK_MAX_N && tiles < 128 && epi != O3V_EPI_SWIGLU) {
+            int splits = 256 / tiles;                       // ~one block per CU
+            const int nk = K / 64;
+            while (splits > 1 && nk / splits < 4) --splits;  // keep >= 4 k-steps per block
+            if (splits > 1 && (size_t)splits * M * N * 4 <= splitk_bytes)
+                return o3v_gemm_bf16_splitk(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, splits, splitk_ws,
+                                            splitk_bytes, s);
+        }
+        return o3v_gemm_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
+    }
     return o3v_gemv_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
 }
 
@@ -102,6 +117,17 @@ extern "C" int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P,
 }
 
 // ------------------------------------------------------------------------------------------------ LLM
+namespace {
+// fp32 partials of the widest split-K linear (q/k/v or hidden outputs; gate/up has enough tiles on its own)
+size_t splitk_bytes(const o3v_llm_desc* d, int rows) {
+    const size_t nq = (size_t)(d->heads + 2 * d->kv_heads) * d->head_dim, nh = d->hidden;
+    const size_t n = nq > nh ? nq : nh;
+    const size_t tiles = (n + 127) / 128;
+    const size_t splits = tiles < 256 ? 256 / tiles + 1 : 1;
+    return splits * rows * n * sizeof(float);
+}
+}  // namespace
+
 extern "C" size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows) {
     if (!d || rows <= 0) return 0;
     const size_t R = rows, H = d->hidden, QD = (size_t)d->heads * d->head_dim, KD = (size_t)d->kv_heads * d->head_dim;
@@ -112,12 +138,15 @@ extern "C" size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows) {
     n += align256(R * QD * 2);              // att
     n += align256(R * d->inter * 2);        // mlp
     n += align256(R * H * 2);               // normed (head)
+    if (rows > 8 && rows <= SPLITK_MAX_ROWS) n += align256(splitk_bytes(d, rows));  // split-K partials of the few-tile GEMMs
     return n;
 }
 
 namespace {
 struct LlmWs {
     char *h, *qkv, *q, *att, *mlp, *normed;
+    float* splitk;
+    size_t splitk_bytes;
 };
 bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w) {
     const size_t R = rows, H = d->hidden, QD = (size_t)d->heads * d->head_dim, KD = (size_t)d->kv_heads * d->head_dim;
@@ -128,6 +157,13 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
     w.att = (char*)cv.take(R * QD * 2);
     w.mlp = (char*)cv.take(R * d->inter * 2);
     w.normed = (char*)cv.take(R * H * 2);
+    w.splitk = nullptr;
+    w.splitk_bytes = 0;
+    if (rows > 8 && rows <= SPLITK_MAX_ROWS) {
+        w.splitk_bytes = splitk_bytes(d, rows);
+        w.splitk = (float*)cv.take(w.splitk_bytes);
+        if (!w.splitk) return false;
+    }
     return w.normed != nullptr;
 }
 }  // namespace
@@ -148,14 +184,14 @@ extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT,
         char* kc = (char*)kcache + l * layer_stride;
         char* vc = (char*)vcache + l * layer_stride;
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
-        TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
+        TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes));
         TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
         TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
                            (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
-        TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes));
         TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s));
-        TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s));
+        TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes));
     }
     return O3V_OK;
 }

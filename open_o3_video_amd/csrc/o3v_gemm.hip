@@ -18,6 +18,7 @@
 #define EPI_RESIDUAL 1
 #define EPI_GELU 2
 #define EPI_SWIGLU 3
+#define EPI_PARTIAL 5  // split-K pass of the MFMA GEMM: raw fp32 tile to the workspace, epilogue in the reduce kernel
 #define EPI_QKVROPE 4  // decode only: bias, M-RoPE, write q / append k,v to the cache (TF:557-599, :652-664)
 
 namespace {
@@ -73,15 +74,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
-    stage_tile(A, lda, m0, M, 0, smem, wave, lane);
-    stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    // split-K (EPI_PARTIAL): blockIdx.y owns k-steps [t0, t1)
+    const int nk_all = K / BK;
+    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t0 = (EPI == EPI_PARTIAL) ? (int)blockIdx.y * per_split : 0;
+    const int nk = (EPI == EPI_PARTIAL) ? (t0 + per_split < nk_all ? t0 + per_split : nk_all) : nk_all;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (t0 < nk) {
+        stage_tile(A, lda, m0, M, t0 * BK, smem, wave, lane);
+        stage_tile(W, ldw, n0, N, t0 * BK, smem + TILE_BYTES, wave, lane);
+    }
     __syncthreads();  // emits vmcnt(0) for the pending LDS-DMA, then the barrier
 
-    const int fr = lane & 15, fg = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        char* cur = smem + (t & 1) * 2 * TILE_BYTES;
-        char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    for (int t = t0; t < nk; ++t) {
+        char* cur = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
+        char* nxt = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
         if (t + 1 < nk) {
             stage_tile(A, lda, m0, M, (t + 1) * BK, nxt, wave, lane);
             stage_tile(W, ldw, n0, N, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
@@ -109,6 +116,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     }
 
     // ---- epilogue.  C/D map of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
+    if (EPI == EPI_PARTIAL) {
+        float* part = reinterpret_cast<float*>(out) + (size_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+                    if (m < M && n < N) part[(size_t)m * N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     // Fast path: the wave's 64x64 fp32 sub-tile goes through LDS (row stride 68 floats: the two 32-lane halves of a
     // ds_write_b32 land on disjoint banks) and comes back row-wise, 8 consecutive columns per lane, so bias / residual are
     // 16-byte loads and every output row segment is a 16-byte store of a full 128-byte line per 8 lanes.
@@ -815,6 +837,57 @@ int launch_gemv_m(const GemvArgs& a) {
 }
 
 }  // namespace
+
+namespace {
+// Sum of the split-K partials in split order (deterministic) + the bias / residual / GELU epilogue of gemm_bf16_kernel.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ out, int ldo, int ldr) {
+    const size_t total = (size_t)M * N, stride = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += part[(size_t)s * stride + i];
+        if (bias) v += bf2f(bias[n]);
+        if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
+        if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+        out[(size_t)m * ldo + n] = f2bf(v);
+    }
+}
+}  // namespace
+
+// The MFMA GEMM for row counts too small to fill the chip with output tiles (a prompt suffix behind a cached prefix:
+// 9..128 rows, N/128 = 28..36 tiles on 256 CUs): K is split across `splits` blocks per tile, fp32 partials go through
+// `workspace` (splits * M * N floats) and a second kernel reduces them in a fixed order and applies the epilogue.
+extern "C" int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N,
+                                    int K, int lda, int ldw, int ldo, int ldr, int epilogue, int splits, float* workspace,
+                                    size_t ws_bytes, hipStream_t stream) {
+    if (!A || !W || !out || !workspace || M <= 0 || N <= 0 || K <= 0 || splits < 1) return O3V_ERR_ARG;
+    if ((K % BK) || (lda & 7) || (ldw & 7)) return O3V_ERR_SHAPE;
+    if (epilogue != EPI_NONE && epilogue != EPI_RESIDUAL && epilogue != EPI_GELU) return O3V_ERR_ARG;
+    if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
+    if (splits > K / BK) splits = K / BK;
+    if (ws_bytes < (size_t)splits * M * N * sizeof(float)) return O3V_ERR_WORKSPACE;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    O3V_KLAUNCH((gemm_bf16_kernel<EPI_PARTIAL>), dim3(tiles_m * tiles_n, splits), dim3(256), 4 * 64 * 68 * 4, stream,
+                (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)workspace, M, N, K, lda,
+                ldw, N, 0, tiles_m, tiles_n);
+    const int rb = (int)(((size_t)M * N + 255) / 256);
+    const dim3 rg(rb < 2048 ? rb : 2048);
+#define O3V_RK(E)                                                                                                        \
+    O3V_KLAUNCH((splitk_reduce_kernel<E>), rg, dim3(256), 0, stream, (const float*)workspace, splits, M, N, (const bf16_t*)bias, \
+                (const bf16_t*)res, (bf16_t*)out, ldo, ldr)
+    if (epilogue == EPI_NONE)
+        O3V_RK(EPI_NONE);
+    else if (epilogue == EPI_RESIDUAL)
+        O3V_RK(EPI_RESIDUAL);
+    else
+        O3V_RK(EPI_GELU);
+#undef O3V_RK
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
 
 extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                              int lda, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {

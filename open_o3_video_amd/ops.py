@@ -36,6 +36,17 @@ def gemm(a, w, bias=None, res=None, epi=EPI_NONE, force=None):
     return out
 
 
+def gemm_splitk(a, w, bias=None, res=None, epi=EPI_NONE, splits=8):
+    """Split-K form of `gemm` for few-tile shapes (epilogues NONE / RESIDUAL / GELU)."""
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device=a.device)
+    _lib.call("o3v_gemm_bf16_splitk", _p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+              0 if res is None else res.stride(0), epi, splits, _p(ws), ws.numel() * 4, _s())
+    return out
+
+
 def vit_rope_(qkv, cos, sin, H, D):
     _lib.call("o3v_vit_rope", _p(qkv), _p(cos), _p(sin), qkv.shape[0], H, D, _s())
     return qkv

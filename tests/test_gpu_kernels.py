@@ -89,6 +89,26 @@ def test_gemm_epilogues(dev, M, N, K):
     close_bf16(r2, _epi_ref(acc, None, res, ops.EPI_RESIDUAL))
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(64, 3584, 3584, 8), (9, 4608, 3584, 7), (128, 3584, 18944, 9), (40, 200, 448, 3),
+                                           (17, 128, 64, 4), (100, 1280, 1280, 1)])
+def test_gemm_splitk(dev, M, N, K, splits):
+    """Split-K form used for a prompt suffix behind a cached prefix (9..128 rows): same epilogues, same tolerance, and
+    bit-identical from run to run (the partials are reduced in split order, no atomics)."""
+    from open_o3_video_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    acc = a.float() @ w.float().t()
+    for epi, b, r in [(ops.EPI_NONE, None, None), (ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, bias, res),
+                      (ops.EPI_GELU, bias, None)]:
+        out = ops.gemm_splitk(a, w, b, r, epi, splits)
+        close_bf16(out, _epi_ref(acc, b, r, epi))
+        assert torch.equal(out, ops.gemm_splitk(a, w, b, r, epi, splits))
+        close_bf16(out, ops.gemm(a, w, b, r, epi, force="gemm").float(), ulps=1, atol=1e-3, frac=0.999)
+
+
 def _swiglu_case(dev, M, I, K, ipad, seed):
     from open_o3_video_amd import ops
     from open_o3_video_amd.weights import pack_gate_up

@@ -54,15 +54,13 @@ if "vstar5" in which:
     # the V-STAR harness asks 5 questions per video (R:eval/test/test_vstar_multi_images.py:511-544); frame
     # block first, then a ~64-token question; 128 greedy tokens each.  With / without visual + prefix-K/V reuse.
     tpf = (224 // 28) * (420 // 28)
-    base = build_prompt(cfg, 32, tpf, 4490)
+    base = build_prompt(cfg, 32, tpf, 4490 - 64)
     g = torch.Generator(device=dev).manual_seed(1)
     frames = torch.randint(0, 256, (32, 3, 224, 420), generator=g, dtype=torch.uint8, device=dev)
     rng = __import__("numpy").random.default_rng(5)
     qs = []
     for q in range(5):
-        ids = list(base)
-        ids[-64:] = [int(t) for t in rng.integers(1000, 150000, 64)]
-        qs.append(ids)
+        qs.append(list(base) + [int(t) for t in rng.integers(1000, 150000, 64)])   # frame block, then the question
     for reuse in (False, True):
         eng.drop_prefix_cache()
         eng.generate([qs[0]], None, frames=frames, max_new_tokens=4)  # warm-up (code paths, allocator)
@@ -76,7 +74,9 @@ if "vstar5" in which:
                 vis = eng.vit_forward(px, grid)
             if reuse:
                 out = eng.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=128, repetition_penalty=1.05,
-                                   prefix_key="video", return_margins=False)
+                                   prefix_key="video", return_margins=False, sync_timings=bool(os.environ.get("O3V_STAGE_TIMES")))
+                if os.environ.get("O3V_STAGE_TIMES"):
+                    print({k: round(v, 2) for k, v in out.timings.items()}, flush=True)
             else:
                 out = eng.generate([ids], None, frames=frames, max_new_tokens=128, repetition_penalty=1.05, return_margins=False)
             reused += out.timings["prefix_tokens_reused"]
@@ -85,6 +85,36 @@ if "vstar5" in which:
         print(json.dumps({"config": f"V-STAR 5 questions/video, 128 tok each, reuse={reuse}", "S": len(base), "wall_s": round(dt, 3),
                           "videos_per_min": round(60 / dt, 1), "questions_per_s": round(5 / dt, 2),
                           "prefix_tokens_reused": int(reused)}), flush=True)
+
+if "tts16" in which:
+    # BASELINE config #5 (test-time scaling, N=16 chains of one 32-frame question, R:eval/test/test_videomme.py:129-226):
+    # two groups of 8 sampled rows; the second group reuses the whole prompt K/V.  256 tokens per chain.  The reference
+    # runs 16 sequential generate calls, each with its own ViT pass and prefill.
+    from open_o3_video_amd import tts
+    tpf = (224 // 28) * (420 // 28)
+    ids = build_prompt(cfg, 32, tpf, 4490)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (32, 3, 224, 420), generator=g, dtype=torch.uint8, device=dev)
+    kw = dict(max_new_tokens=256, do_sample=True, top_p=0.95, temperature=1.0, repetition_penalty=1.05, seed=3,
+              return_margins=False)
+    for rep in range(2):
+        eng.drop_prefix_cache()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        px, grid = eng.pixels_from_frames(frames)
+        vis = eng.vit_forward(px, grid)
+        reused = 0
+        for i0 in (0, 8):
+            out = eng.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, num_return_sequences=8,
+                               row_ids=list(range(i0, i0 + 8)), prefix_key="q", **kw)
+            reused += out.timings["prefix_tokens_reused"]
+        claims = [{"obj": "o", "box_xyxy": [20 + 3 * i, 10 + 2 * i, 200 + 5 * i, 150 + 3 * i], "t_sec": float(i)} for i in range(10)]
+        crops = tts.extract_and_crop(frames, 1.0, claims)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"config": "TTS N=16 chains x 256 tok, 32 frames (config #5 sampling side)", "S": len(ids), "wall_s": round(dt, 3),
+                      "tokens_per_s": round(16 * 256 / dt, 1), "questions_per_min": round(60 / dt, 1),
+                      "prefix_tokens_reused": int(reused), "crops": list(crops.shape)}), flush=True)
 
 if "3b" in which:
     # BASELINE config #1 shapes: Qwen2.5-VL-3B dims (tied embeddings, GQA 8:1), 4 frames at EVAL-RES, 256 new tokens
