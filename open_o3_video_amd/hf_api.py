@@ -191,5 +191,14 @@ class Qwen2_5_VLForConditionalGeneration:
         return torch.cat(out, dim=0)
 
 
+    @torch.no_grad()
+    def completion_logps(self, prompt_ids, prompt_mask, completion_ids, pixel_values=None, image_grid_thw=None):
+        """`_get_per_token_logps(model, cat([prompt]*G, completions), ...)[:, prompt_length-1:]` (R:grpo_trainer.py:371-384,
+        :612-613) for the G completions of one prompt, f32 [G, T]: one ViT pass, one prompt prefill, logits only where kept
+        (see O3VEngine.completion_logps)."""
+        return self.engine.completion_logps(prompt_ids, completion_ids, prompt_mask, pixel_values=pixel_values,
+                                            image_grid_thw=image_grid_thw)
+
+
 # the north-star text names the Qwen2-VL class; both resolve to the same engine
 Qwen2VLForConditionalGeneration = Qwen2_5_VLForConditionalGeneration

@@ -112,10 +112,10 @@ class GroupRollout:
         S = ids.shape[1]
         comp = pc[:, S:]
         cmask = completion_mask(comp, self.eos)
-        full_mask = torch.cat([mask.to(pc.device).repeat_interleave(self.G, dim=0), torch.ones_like(comp)], dim=1)
-        rep = lambda t: None if t is None else torch.as_tensor(t).repeat(pc.shape[0], *([1] * (torch.as_tensor(t).dim() - 1)))
-        lp = self.model.per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
-        ref = (self.ref_model or self.model).per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
+        # per-token log-probs of the completions under the policy and the reference model (R:…:601-632): the G rows share
+        # the prompt, so each model runs the ViT and the prompt once and the lm_head only over the G x T kept positions
+        lp = self._logps(self.model, ids, mask, comp, pv, grid, pc)
+        ref = lp if self.ref_model is None else self._logps(self.ref_model, ids, mask, comp, pv, grid, pc)
         kl = per_token_kl(ref, lp)
         texts = self.decode(comp)
         completions = [[{"role": "assistant", "content": t}] for t in texts]
@@ -130,6 +130,15 @@ class GroupRollout:
         res = RolloutResult(pc, comp, cmask, lp, ref, kl, rpf, rewards, adv, loss, texts)
         res.metrics = self.gather_metrics(res, std)
         return res
+
+    def _logps(self, model, ids, mask, comp, pv, grid, pc):
+        if hasattr(model, "completion_logps"):
+            return model.completion_logps(ids, mask, comp, pv, grid)
+        # any other HF-style model: the reference's own formulation
+        S = ids.shape[1]
+        full_mask = torch.cat([torch.as_tensor(mask).to(pc.device).repeat_interleave(self.G, dim=0), torch.ones_like(comp)], dim=1)
+        rep = lambda t: None if t is None else torch.as_tensor(t).repeat(pc.shape[0], *([1] * (torch.as_tensor(t).dim() - 1)))
+        return model.per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
 
     def gather_metrics(self, res: RolloutResult, std: torch.Tensor) -> Dict[str, float]:
         """One all_gather of [G, n_funcs+4] replaces six gather_for_metrics (R:…:711-738)."""

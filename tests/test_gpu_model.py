@@ -249,3 +249,37 @@ def test_group_rollout_shared_prefix_attention(need_gpu, golden_dir):
     s_tail = eng.generate(g["input_ids"], None, num_return_sequences=4, do_sample=True, top_p=0.95, seed=5, row_ids=[4, 5, 6, 7],
                           **kw).sequences
     assert torch.equal(s_tail, s_on[4:8])
+
+
+def test_completion_logps_shared_prompt(need_gpu):
+    """G completions of one prompt (R:grpo_trainer.py:371-384, :612-613): one ViT pass + one prompt prefill + the
+    completion tokens behind the shared prompt K/V + lm_head on the kept positions only, against (a) the CPU oracle run
+    row by row on the concatenated sequences and (b) the engine's own full-sequence formulation."""
+    from oracle import index_ref, model_ref
+    cfg = fm.medium_config()
+    W = fm.make_weights(cfg, 6)
+    frames = fm.make_frames(2, 56, 84, seed=9)
+    eng = build_engine(cfg, W)
+    px, grid = eng.pixels_from_frames(frames)
+    ids = fm.make_prompt(cfg, [tuple(r) for r in grid.tolist()], seed=9)
+    S, G, T = len(ids), 3, 7
+    gen = torch.Generator().manual_seed(3)
+    comp = torch.randint(10, 3000, (G, T), generator=gen)
+    comp[1, 4:] = cfg["pad_token_id"]                       # a finished row padded after its EOS: still scored (masked later)
+    mean = np.asarray(index_ref.CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.asarray(index_ref.CLIP_STD, dtype=np.float32)[None, :, None, None]
+    xf = ((frames.numpy().astype(np.float64) / 255.0).astype(np.float32) - mean) / std
+    pv, _ = index_ref.patchify_frames(xf.astype(np.float32))
+    ours = eng.completion_logps(ids, comp, frames=frames).cpu()
+    assert ours.shape == (G, T) and ours.dtype == torch.float32
+    for g in range(G):
+        seq = torch.cat([torch.tensor(ids), comp[g]])[None]
+        ref = model_ref.per_token_logps(model_ref.full_logits(W, cfg, seq, None, torch.from_numpy(pv), grid), seq)[0, S - 1:]
+        full = eng.per_token_logps(eng.forward_logits(seq.numpy(), None, frames=frames), seq).cpu()[0, S - 1:]
+        assert (ours[g] - ref).abs().max().item() < 0.1, g
+        assert (ours[g] - full).abs().max().item() < 0.1, g
+    # chunked head: any chunk size gives the same numbers; T == 1 touches only the prompt's last position
+    again = eng.completion_logps(ids, comp, frames=frames, rows_per_chunk=16).cpu()
+    assert torch.equal(again, ours)
+    one = eng.completion_logps(ids, comp[:, :1], frames=frames).cpu()
+    assert (one[:, 0] - ours[:, 0]).abs().max().item() < 1e-6

@@ -86,6 +86,31 @@ if "vstar5" in which:
                           "videos_per_min": round(60 / dt, 1), "questions_per_s": round(5 / dt, 2),
                           "prefix_tokens_reused": int(reused)}), flush=True)
 
+if "logps" in which:
+    # log-prob pass of the GSPO step (R:grpo_trainer.py:601-632) for G=8 completions of 256 tokens behind the 4490-token
+    # prompt: shared-prompt formulation vs the reference's row-by-row full-sequence formulation on the same engine
+    tpf = (224 // 28) * (420 // 28)
+    ids = build_prompt(cfg, 32, tpf, 4490)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (32, 3, 224, 420), generator=g, dtype=torch.uint8, device=dev)
+    comp = torch.randint(1000, 150000, (8, 256), generator=torch.Generator().manual_seed(2))
+    for name in ("shared", "rowwise"):
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if name == "shared":
+                lp = eng.completion_logps(ids, comp, frames=frames)
+            else:
+                rows = []
+                for r in range(8):
+                    seq = torch.cat([torch.tensor(ids), comp[r]])[None]
+                    rows.append(eng.per_token_logps(eng.forward_logits(seq.numpy(), None, frames=frames), seq)[:, len(ids) - 1:])
+                lp2 = torch.cat(rows)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(json.dumps({"config": f"completion log-probs G=8 x 256 tok, S=4490, {name}", "wall_ms": round(dt * 1e3, 1)}), flush=True)
+    print(json.dumps({"max_abs_diff_between_formulations": round((lp - lp2).abs().max().item(), 4)}), flush=True)
+
 if "tts16" in which:
     # BASELINE config #5 (test-time scaling, N=16 chains of one 32-frame question, R:eval/test/test_videomme.py:129-226):
     # two groups of 8 sampled rows; the second group reuses the whole prompt K/V.  256 tokens per chain.  The reference
