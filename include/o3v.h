@@ -62,6 +62,13 @@ int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, o3
 int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
                  const float* std3, o3v_stream_t stream);
 
+/* fetch_video's frame resize, R:src/r1-v/src/open_r1/vision_process.py:310-315 (torchvision resize, BICUBIC, antialias ==
+ * ATen _upsample_bicubic2d_aa): src [planes,H_in,W_in] uint8 or f32 -> dst f32 [planes,H_out,W_out]; tmp f32
+ * [planes,H_in,W_out].  Tap tables per output column / row ({x,y}min, {x,y}size, normalised weights [out][k]) are built on
+ * the host (open_o3_video_amd/vision_process.py aa_tables).  uint8 sources are rounded and clamped like torchvision. */
+int o3v_resize_bicubic_aa(const void* src, int is_u8, float* tmp, float* dst, int planes, int H_in, int W_in, int H_out,
+                          int W_out, const int* xmin, const int* xsize, const float* xw, int xk, const int* ymin,
+                          const int* ysize, const float* yw, int yk, o3v_stream_t stream);
 /* crop_box of the test-time-scaling loop, R:eval/tts.py:54-75: boxes int32 [n][5] = {frame, x1, y1, x2, y2} (clipped,
  * non-empty) of uint8 frames [T,3,H,W] -> uint8 [n,3,H,W], cv2.resize(float32 crop, (W,H), INTER_LINEAR).astype(uint8) */
 int o3v_crop_resize_bilinear(const void* frames, const int* boxes, void* out, int n, int T, int H, int W,

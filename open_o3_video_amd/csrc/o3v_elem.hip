@@ -402,6 +402,74 @@ extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Frame resize of fetch_video (R:src/r1-v/src/open_r1/vision_process.py:310-315: torchvision resize, BICUBIC,
+// antialias=True on the [T,3,H,W] frame tensor == ATen _upsample_bicubic2d_aa): separable, width pass then height
+// pass, each output sample a dot product of <= kmax taps whose normalised weights (cubic a = -0.5, support widened by
+// the scale when shrinking) are tabulated once per (in, out) size on the host in float32, exactly as ATen computes them.
+// The taps are accumulated in tap order with separate multiply and add, fp32 throughout; uint8 sources are rounded half
+// to even and clamped to 0..255 at the end (torchvision's uint8 path), the result stays float32 for the patch kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void resize_aa_w_kernel(const TIN* __restrict__ src, float* __restrict__ dst, long rows,
+                                                          int W_in, int W_out, const int* __restrict__ xmin,
+                                                          const int* __restrict__ xsize, const float* __restrict__ w, int kmax) {
+    const long total = rows * W_out;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long row = idx / W_out;
+        const int i = (int)(idx - row * W_out);
+        const TIN* sp = src + row * W_in + xmin[i];
+        const float* wp = w + (size_t)i * kmax;
+        const int n = xsize[i];
+        float t = __fmul_rn((float)sp[0], wp[0]);
+        for (int j = 1; j < n; ++j) t = __fadd_rn(t, __fmul_rn((float)sp[j], wp[j]));
+        dst[idx] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_aa_h_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                          int H_in, int H_out, int W, const int* __restrict__ ymin,
+                                                          const int* __restrict__ ysize, const float* __restrict__ w, int kmax,
+                                                          int round_u8) {
+    const long total = (long)planes * H_out * W;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int x = (int)(idx % W);
+        const long r = idx / W;
+        const int i = (int)(r % H_out);
+        const long pl = r / H_out;
+        const float* sp = src + (pl * H_in + ymin[i]) * W + x;
+        const float* wp = w + (size_t)i * kmax;
+        const int n = ysize[i];
+        float t = __fmul_rn(sp[0], wp[0]);
+        for (int j = 1; j < n; ++j) t = __fadd_rn(t, __fmul_rn(sp[(size_t)j * W], wp[j]));
+        if (round_u8) t = fminf(fmaxf(rintf(t), 0.f), 255.f);
+        dst[idx] = t;
+    }
+}
+
+extern "C" int o3v_resize_bicubic_aa(const void* src, int is_u8, float* tmp, float* dst, int planes, int H_in, int W_in,
+                                     int H_out, int W_out, const int* xmin, const int* xsize, const float* xw, int xk,
+                                     const int* ymin, const int* ysize, const float* yw, int yk, hipStream_t stream) {
+    if (!src || !tmp || !dst || !xmin || !xsize || !xw || !ymin || !ysize || !yw || planes < 0 || H_in <= 0 || W_in <= 0 ||
+        H_out <= 0 || W_out <= 0 || xk <= 0 || yk <= 0)
+        return O3V_ERR_ARG;
+    if (planes == 0) return O3V_OK;
+    const long rows = (long)planes * H_in;
+    long b1 = (rows * W_out + 255) / 256, b2 = ((long)planes * H_out * W_out + 255) / 256;
+    b1 = b1 < 16384 ? b1 : 16384;
+    b2 = b2 < 16384 ? b2 : 16384;
+    if (is_u8)
+        O3V_KLAUNCH(resize_aa_w_kernel<uint8_t>, dim3((int)b1), dim3(256), 0, stream, (const uint8_t*)src, tmp, rows, W_in, W_out,
+                    xmin, xsize, xw, xk);
+    else
+        O3V_KLAUNCH(resize_aa_w_kernel<float>, dim3((int)b1), dim3(256), 0, stream, (const float*)src, tmp, rows, W_in, W_out, xmin,
+                    xsize, xw, xk);
+    O3V_KLAUNCH(resize_aa_h_kernel, dim3((int)b2), dim3(256), 0, stream, (const float*)tmp, dst, planes, H_in, H_out, W_out, ymin,
+                ysize, yw, yk, is_u8);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Test-time-scaling crops (R:eval/tts.py:54-75 crop_box): box [x1,x2) x [y1,y2) of frame f, resized back to the
 // full frame size W x H with OpenCV's INTER_LINEAR on float32 (pixel centres: src = (dst + 0.5) * scale - 0.5,
 // edge replicate, horizontal pass then vertical pass, each a two-term float sum) and truncated to uint8.

@@ -12,6 +12,7 @@ is not installable offline, so the resize numerics are unpinned (DESIGN.md secti
 from __future__ import annotations
 
 import base64
+import functools
 import importlib.util
 import logging
 import math
@@ -193,6 +194,60 @@ def video_pixel_budget(nframes: int, ele: dict):
     if want > cap:
         logger.warning(f"The given max_pixels[{want}] exceeds limit[{cap}].")
     return min_pixels, min(want, cap)
+
+
+@functools.lru_cache(maxsize=64)
+def aa_tables(in_size: int, out_size: int):
+    """Tap tables of ATen's antialiased bicubic resize along one axis (aten/native/cpu/UpSampleKernel.cpp
+    `compute_indices_weights_aa` with the a = -0.5 cubic, align_corners=False), evaluated in float32 like ATen does for a
+    float32 input: (first tap [out] i32, tap count [out] i32, normalised weights [out, kmax] f32).  Consumed by the HIP
+    resize (o3v_resize_bicubic_aa); `F.interpolate(..., mode="bicubic", antialias=True)` is the CPU reference it is
+    tested against."""
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)
+    support = f32(2.0) * scale if scale >= 1 else f32(2.0)
+    invscale = f32(1.0) / scale if scale >= 1 else f32(1.0)
+    kmax = int(np.ceil(support)) * 2 + 1
+    i = np.arange(out_size, dtype=np.float32)
+    center = (scale * (i + f32(0.5))).astype(np.float32)
+    lo = np.maximum((center - support + f32(0.5)).astype(np.float32).astype(np.int64), 0)
+    hi = np.minimum((center + support + f32(0.5)).astype(np.float32).astype(np.int64), in_size)
+    n = (hi - lo).astype(np.int64)
+    j = np.arange(kmax, dtype=np.int64)[None, :]
+    x = (((j + lo[:, None]).astype(np.float32) - center[:, None] + f32(0.5)).astype(np.float32) * invscale).astype(np.float32)
+    ax = np.abs(x)
+    a = f32(-0.5)
+    near = ((((a + f32(2)) * ax - (a + f32(3))).astype(np.float32) * ax).astype(np.float32) * ax + f32(1)).astype(np.float32)
+    far = (((((ax - f32(5)) * ax + f32(8)).astype(np.float32) * ax).astype(np.float32) - f32(4)) * a).astype(np.float32)
+    w = np.where(ax < 1, near, np.where(ax < 2, far, f32(0))).astype(np.float32)
+    w = np.where(j < n[:, None], w, f32(0)).astype(np.float32)
+    tot = np.zeros(out_size, dtype=np.float32)
+    for k in range(kmax):                       # ATen sums the taps in order
+        tot = (tot + w[:, k]).astype(np.float32)
+    w = np.where(tot[:, None] != 0, (w / np.where(tot == 0, f32(1), tot)[:, None]).astype(np.float32), w)
+    return lo.astype(np.int32), n.astype(np.int32), np.ascontiguousarray(w, dtype=np.float32)
+
+
+def resize_frames_device(video: torch.Tensor, size) -> torch.Tensor:
+    """`resize_frames` on the GPU (uint8 / float frames [T,3,H,W] on or off the device -> float32 [T,3,h,w] on the
+    device): the frames never return to the host between decode and the ViT."""
+    import ctypes as C
+    from . import _lib
+    if not torch.cuda.is_available():
+        raise _lib.O3VError("resize_frames_device needs the GPU (resize_frames is the CPU form)")
+    is_u8 = video.dtype == torch.uint8
+    src = video.cuda().contiguous() if is_u8 else video.cuda().float().contiguous()
+    T, Cn, H, W = src.shape
+    h, w = int(size[0]), int(size[1])
+    xt, yt = aa_tables(W, w), aa_tables(H, h)
+    dev = src.device
+    tb = [torch.from_numpy(t).to(dev) for t in (*xt, *yt)]
+    tmp = torch.empty((T * Cn, H, w), dtype=torch.float32, device=dev)
+    out = torch.empty((T, Cn, h, w), dtype=torch.float32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.call("o3v_resize_bicubic_aa", P(src), int(is_u8), P(tmp), P(out), T * Cn, H, W, h, w, P(tb[0]), P(tb[1]), P(tb[2]),
+              xt[2].shape[1], P(tb[3]), P(tb[4]), P(tb[5]), yt[2].shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return out
 
 
 def resize_frames(video: torch.Tensor, size) -> torch.Tensor:

@@ -137,7 +137,7 @@ class LLM:
         # that process_vision_info already sized
         rh, rw = vp.smart_resize(H, W, 28, self.min_pixels, self.max_pixels)
         if (rh, rw) != (H, W):
-            data = vp.resize_frames(data, (rh, rw))
+            data = vp.resize_frames_device(data, (rh, rw))   # antialiased bicubic on the GPU; frames stay on the device
         return data
 
     def _visual_tokens(self, frames: torch.Tensor) -> torch.Tensor:

@@ -630,3 +630,25 @@ def test_sample_top_p_full_vocab(dev, top_p, temp, rep):
     np.testing.assert_allclose(lp.view(-1).numpy(), lsm[o.view(-1)].numpy(), rtol=0, atol=2e-4)
     if top_p >= 0.9:
         assert len(set(o.view(-1).tolist())) > 3
+
+
+@pytest.mark.parametrize("T,H,W,h,w", [(4, 360, 640, 224, 420), (2, 360, 640, 364, 644), (3, 50, 70, 112, 84), (1, 28, 28, 28, 28)])
+def test_resize_bicubic_antialias(dev, T, H, W, h, w):
+    """GPU frame resize against torch's CPU antialiased bicubic (what torchvision's resize runs in fetch_video,
+    R:vision_process.py:310-315).  Float frames: fp32 tolerance; uint8 frames: rounded like torchvision's uint8 path, equal
+    except where the float result sits within rounding error of a .5 tie."""
+    import torch.nn.functional as F
+    from open_o3_video_amd import vision_process as vp
+    g = torch.Generator().manual_seed(H + w)
+    fr = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
+    ref_f = F.interpolate(fr.float(), size=[h, w], mode="bicubic", antialias=True, align_corners=False)
+    out_f = vp.resize_frames_device(fr.float(), (h, w)).cpu()
+    assert out_f.shape == ref_f.shape and out_f.dtype == torch.float32
+    assert (out_f - ref_f).abs().max().item() < 1e-3
+    ref_u = vp.resize_frames(fr, (h, w))                      # CPU form: round + clamp
+    out_u = vp.resize_frames_device(fr, (h, w)).cpu()
+    d = (out_u - ref_u).abs()
+    assert d.max().item() <= 1.0 and (d > 0).float().mean().item() < 1e-4
+    assert out_u.min().item() >= 0 and out_u.max().item() <= 255 and torch.equal(out_u, out_u.round())
+    if (h, w) == (H, W):
+        assert torch.equal(out_u, fr.float())

@@ -88,3 +88,22 @@ def test_resized_height_width_and_budget():
     mn, mx = vp.video_pixel_budget(768, {})
     assert mn == 128 * 784 and mx == int(mn * 1.05)   # many frames: floor at 1.05 * min_pixels (R:...:291)
     assert vp.video_pixel_budget(32, {"max_pixels": 50176})[1] == 50176
+
+
+def test_aa_tables_reproduce_torch_bicubic_antialias():
+    """Tap tables handed to the HIP resize kernel against torch's own antialiased bicubic (the ATen kernel torchvision's
+    resize calls, R:vision_process.py:310-315) along one axis: shrink (TRAIN-RES 640->420, 360->224), enlarge, identity."""
+    import torch.nn.functional as F
+    from open_o3_video_amd.vision_process import aa_tables
+    g = torch.Generator().manual_seed(0)
+    for n_in, n_out in [(640, 420), (360, 224), (100, 250), (37, 37), (1080, 364), (5, 3)]:
+        x = torch.rand(1, 1, 1, n_in, generator=g) * 255
+        ref = F.interpolate(x, size=(1, n_out), mode="bicubic", antialias=True)[0, 0, 0].numpy()
+        lo, n, w = aa_tables(n_in, n_out)
+        assert lo.dtype == np.int32 and w.dtype == np.float32 and (lo >= 0).all() and (lo + n <= n_in).all()
+        assert np.abs(w.sum(1) - 1).max() < 1e-6
+        xs = x[0, 0, 0].numpy()
+        out = np.array([sum(np.float32(xs[lo[i] + j] * w[i, j]) for j in range(n[i])) for i in range(n_out)], dtype=np.float32)
+        assert np.abs(out - ref).max() < 5e-4, (n_in, n_out)
+    lo, n, w = aa_tables(37, 37)
+    assert (n <= 5).all() and np.allclose(w.max(1), 1.0)            # same size: the centre tap only
