@@ -86,6 +86,32 @@ if "vstar5" in which:
                           "videos_per_min": round(60 / dt, 1), "questions_per_s": round(5 / dt, 2),
                           "prefix_tokens_reused": int(reused)}), flush=True)
 
+if "frames" in which:
+    # host-buffer boundary: raw decoded frames uint8 [32,3,360,640] in host memory -> H2D -> antialiased bicubic resize to
+    # TRAIN-RES 224x420 -> rescale/normalise/patchify -> ViT, vs the same with the frames already resident and resized
+    from open_o3_video_amd import vision_process as vp
+    raw = torch.randint(0, 256, (32, 3, 360, 640), dtype=torch.uint8).pin_memory()
+    t_cpu0 = time.perf_counter()
+    ref = vp.resize_frames(raw, (224, 420))
+    t_cpu = time.perf_counter() - t_cpu0
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d = raw.to(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rs = vp.resize_frames_device(d, (224, 420))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        px, grid = eng.pixels_from_frames(rs)
+        vis = eng.vit_forward(px, grid)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+    print(json.dumps({"config": "frame pipeline 32x3x360x640 u8 host -> ViT tokens", "h2d_ms": round((t1 - t0) * 1e3, 2),
+                      "resize_ms": round((t2 - t1) * 1e3, 3), "patchify_vit_ms": round((t3 - t2) * 1e3, 2),
+                      "cpu_resize_ms": round(t_cpu * 1e3, 1), "max_abs_diff_vs_cpu_resize": float((rs.cpu() - ref).abs().max())}),
+          flush=True)
+
 if "logps" in which:
     # log-prob pass of the GSPO step (R:grpo_trainer.py:601-632) for G=8 completions of 256 tokens behind the 4490-token
     # prompt: shared-prompt formulation vs the reference's row-by-row full-sequence formulation on the same engine
