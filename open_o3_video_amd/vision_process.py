@@ -349,3 +349,45 @@ def frames_as_images_prompt(prompt: str, nframes: int, fps: float, style: str = 
     if style == "trainer":
         fp += f"The video is in total {int(nframes / fps)} seconds.\n"
     return prompt.replace(VIDEO_TAG, fp)
+
+
+def interleave_key_frames(video: torch.Tensor, fps: float, key_frames, prompt: Optional[str] = None):
+    """The trainer's key-frame branch (R:grpo_trainer.py:495-538): the dataset's key frames (each `{"time": seconds,
+    "image": PIL image | path | array}`), resized to the video frames' (W, H) with PIL's default filter like
+    `kf.convert('RGB').resize(image_size)` (:505-507), are spliced between the sampled frames -- a key frame goes in as soon
+    as the whole second of the next video frame has reached `round(time)` -- and every frame gets its
+    `Frame i at ts:` line.  -> (frames [T+K',3,H,W] in the video's dtype, frame prompt or, when `prompt` is given, the
+    prompt with the video placeholder replaced).  Key frames later than the last video frame are dropped, as in the
+    reference."""
+    from PIL import Image
+    T, _, H, W = video.shape
+    kfs = []
+    for kf in key_frames:
+        im = kf["image"] if "image" in kf else kf["path"]
+        if isinstance(im, str):
+            im = Image.open(im)
+        if not hasattr(im, "convert"):
+            arr = np.asarray(im)
+            if arr.ndim == 3 and arr.shape[0] == 3 and arr.shape[-1] != 3:
+                arr = arr.transpose(1, 2, 0)
+            im = Image.fromarray(arr.astype(np.uint8))
+        arr = np.array(im.convert("RGB").resize((W, H)))
+        kfs.append((round(kf["time"]), torch.from_numpy(np.transpose(arr, (2, 0, 1))).to(video.dtype)))
+    fp, frames = "", []
+    kf_idx = ori_idx = 0
+    frame_idx = 1
+    while ori_idx < T:
+        time_now = int(ori_idx / fps)
+        if kf_idx < len(kfs) and time_now >= kfs[kf_idx][0]:
+            frames.append(kfs[kf_idx][1])
+            time_now = round(kfs[kf_idx][0], 1)
+            kf_idx += 1
+        else:
+            frames.append(video[ori_idx])
+            time_now = round(ori_idx / fps, 1)
+            ori_idx += 1
+        fp += f"Frame {frame_idx} at {time_now}s: {IMAGE_TAG}\n"
+        frame_idx += 1
+    fp += f"The video is in total {int(T / fps)} seconds.\n"
+    out = torch.stack(frames)
+    return out, (fp if prompt is None else prompt.replace(VIDEO_TAG, fp))

@@ -155,3 +155,28 @@ def frame_prompt_vstar(timestamps):
 def replace_video_pad(prompt, frame_prompt):
     # R:grpo_trainer.py:487 ; R:eval/inference_example.py:72
     return prompt.replace(VID, frame_prompt)
+
+
+def frame_prompt_trainer_keyframes(n_video_frames, fps, key_frame_times):
+    """R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:513-533: sampled video frames with the dataset's key frames spliced
+    in.  `key_frame_times` are the already rounded key-frame times (`round(key_frame["time"])`, :509) in dataset order.
+    Returns (frame prompt, order) where order lists ("kf", k) / ("video", i) per emitted frame.  A key frame is emitted
+    as soon as the integer second of the next video frame has reached its time; key frames still pending when the video
+    frames run out are dropped."""
+    prompt, order = "", []
+    kf_idx = ori_idx = 0
+    frame_idx = 1
+    while ori_idx < n_video_frames:
+        time_now = int(ori_idx / fps)
+        if kf_idx < len(key_frame_times) and time_now >= key_frame_times[kf_idx]:
+            order.append(("kf", kf_idx))
+            time_now = round(key_frame_times[kf_idx], 1)
+            kf_idx += 1
+        else:
+            order.append(("video", ori_idx))
+            time_now = round(ori_idx / fps, 1)
+            ori_idx += 1
+        prompt += f"Frame {frame_idx} at {time_now}s: <|vision_start|><|image_pad|><|vision_end|>\n"
+        frame_idx += 1
+    prompt += f"The video is in total {int(n_video_frames / fps)} seconds.\n"
+    return prompt, order

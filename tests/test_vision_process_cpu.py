@@ -107,3 +107,41 @@ def test_aa_tables_reproduce_torch_bicubic_antialias():
         assert np.abs(out - ref).max() < 5e-4, (n_in, n_out)
     lo, n, w = aa_tables(37, 37)
     assert (n <= 5).all() and np.allclose(w.max(1), 1.0)            # same size: the centre tap only
+
+
+def test_key_frame_interleave_matches_trainer_loop():
+    """R:grpo_trainer.py:495-538 (transcribed in oracle/vision_policy.py): order of spliced key frames, the per-frame time
+    stamps, the closing duration line, dropped late key frames; plus a hand-worked case."""
+    from PIL import Image
+    from oracle import vision_policy as vpo
+    from open_o3_video_amd import vision_process as vp
+    rng = np.random.default_rng(0)
+    video = torch.from_numpy(rng.integers(0, 256, (6, 3, 28, 56), dtype=np.uint8)).float()
+    kf_img = Image.fromarray(rng.integers(0, 256, (40, 30, 3), dtype=np.uint8))
+    # hand-worked: fps 2 -> video frames at 0, 0.5, 1, 1.5, 2, 2.5 s; key frames at 0.6 s (round -> 1) and 2.2 s (-> 2)
+    frames, fp = vp.interleave_key_frames(video, 2.0, [{"time": 0.6, "image": kf_img}, {"time": 2.2, "image": kf_img}])
+    lines = fp.strip().split("\n")
+    stamps = [l.split(" at ")[1].split(":")[0] for l in lines[:-1]]
+    assert stamps == ["0.0s", "0.5s", "1s", "1.0s", "1.5s", "2s", "2.0s", "2.5s"]
+    assert lines[-1] == "The video is in total 3 seconds." and frames.shape == (8, 3, 28, 56) and frames.dtype == video.dtype
+    assert torch.equal(frames[0], video[0]) and torch.equal(frames[3], video[2]) and torch.equal(frames[7], video[5])
+    exp_kf = torch.from_numpy(np.array(kf_img.resize((56, 28))).transpose(2, 0, 1)).float()
+    assert torch.equal(frames[2], exp_kf) and torch.equal(frames[5], exp_kf)
+    # against the transcription on random schedules (incl. key frames past the end, several at one second, none)
+    for trial in range(40):
+        T = int(rng.integers(1, 20))
+        fps = float(rng.choice([0.5, 1.0, 1.4527, 2.0, 3.0]))
+        times = sorted(rng.uniform(0, T / fps + 2, int(rng.integers(0, 5))).tolist())
+        vid = torch.zeros(T, 3, 28, 28)
+        vid[:, 0, 0, 0] = torch.arange(T).float()
+        kfs = [{"time": t, "image": Image.new("RGB", (8, 8), (k + 1, 0, 0))} for k, t in enumerate(times)]
+        got_frames, got_fp = vp.interleave_key_frames(vid, fps, kfs)
+        exp_fp, order = vpo.frame_prompt_trainer_keyframes(T, fps, [round(t) for t in times])
+        assert got_fp == exp_fp and got_frames.shape[0] == len(order)
+        for f, (kind, idx) in zip(got_frames, order):
+            if kind == "video":
+                assert f[0, 0, 0].item() == idx and f[1].abs().sum() == 0
+            else:
+                assert f[0, 0, 0].item() == idx + 1 and f[0].min().item() == idx + 1
+    out, text = vp.interleave_key_frames(video, 2.0, [], prompt="a " + vp.VIDEO_TAG + " b")
+    assert torch.equal(out, video) and text == "a " + vp.frames_as_images_prompt(vp.VIDEO_TAG, 6, 2.0) + " b"
