@@ -61,6 +61,15 @@ def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def all_gather_padded(t: torch.Tensor, width: int, fill) -> torch.Tensor:
+    """[n, T_local] per rank (T_local may differ) -> [world*n, width]: right-pad to `width`, one collective."""
+    if t.shape[1] > width:
+        raise ValueError("width smaller than a local tensor")
+    p = torch.full((t.shape[0], width), fill, dtype=t.dtype, device=t.device)
+    p[:, :t.shape[1]] = t
+    return all_gather_records(p)
+
+
 def gather_objects(obj) -> list:
     r, w = world()
     if w == 1:

@@ -115,11 +115,14 @@ class Qwen2_5_VLForConditionalGeneration:
         if G > MAX_ROWS:
             raise ValueError(f"num_return_sequences={G} > {MAX_ROWS}")
         step = max(1, MAX_ROWS // G)
+        # first global completion index of this call: a rank that decodes rows row0..row0+G-1 of a larger group keys its
+        # sampler by those indices, so the group is the same whichever ranks produced its rows (partitioning B)
+        row0 = int(kw.get("row_id_offset", _get(gc, "row_id_offset", 0)))
         for b0 in range(0, B, step):
             b1 = min(B, b0 + step)
             pv, gr = self._cat_pixels(per_prompt_pixels[b0:b1])
             out = self.engine.generate(ids[b0:b1], None if mask is None else mask[b0:b1], pixel_values=pv, image_grid_thw=gr,
-                                       num_return_sequences=G, row_ids=list(range(b0 * G, b1 * G)), return_margins=False,
+                                       num_return_sequences=G, row_ids=list(range(row0 + b0 * G, row0 + b1 * G)), return_margins=False,
                                        **common)
             rows.append(out.sequences)
         L = max(r.shape[1] for r in rows)

@@ -84,12 +84,17 @@ class GroupRollout:
                  eos_token_id: int, pad_token_id: int, ref_model=None, num_generations: int = 4,
                  max_completion_length: int = 768, max_prompt_length: Optional[int] = 16384, beta: float = 0.04,
                  epsilon_low: float = 0.2, epsilon_high: float = 0.2, temperature: float = 1.0, top_p: float = 0.95,
-                 gspo: bool = True):
+                 gspo: bool = True, group_parallel: bool = False):
         self.model, self.ref_model = model, ref_model
         self.reward_funcs = list(reward_funcs)
         self.decode = decode
         self.eos, self.pad = eos_token_id, pad_token_id
         self.G, self.T = num_generations, max_completion_length
+        # group_parallel: the G completions of ONE prompt are sharded over the ranks (G/world rows each, every rank runs the
+        # ViT and the prompt prefill itself -- cheap next to the decode) and the per-sample rewards / log-probs are
+        # all-gathered, because the group mean / std of the advantages spans all G (SURVEY 8e partitioning B; BASELINE
+        # config #3).  Default (False) is the reference's own layout: one prompt with all its G completions per rank.
+        self.group_parallel = bool(group_parallel)
         self.max_prompt_length = max_prompt_length
         self.beta, self.el, self.eh = beta, epsilon_low, epsilon_high
         self.temperature, self.top_p, self.gspo = temperature, top_p, gspo
@@ -104,9 +109,14 @@ class GroupRollout:
             ids, mask = ids[:, -self.max_prompt_length:], mask[:, -self.max_prompt_length:]
         pv, grid = prompt_inputs.get("pixel_values"), prompt_inputs.get("image_grid_thw")
         from .hf_api import GenerationConfigLike
+        rank, world = o3v_dist.world()
+        sharded = self.group_parallel and world > 1
+        if sharded and self.G % world:
+            raise ValueError(f"num_generations={self.G} is not divisible by the {world} ranks of the group")
+        G_local = self.G // world if sharded else self.G
         gc = GenerationConfigLike(max_new_tokens=self.T, do_sample=True, top_p=self.top_p, temperature=self.temperature,
-                                  num_return_sequences=self.G, pad_token_id=self.pad, eos_token_id=self.eos,
-                                  repetition_penalty=1.0)
+                                  num_return_sequences=G_local, pad_token_id=self.pad, eos_token_id=self.eos,
+                                  repetition_penalty=1.0, row_id_offset=rank * G_local if sharded else 0)
         pc = self.model.generate(input_ids=ids, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
                                  generation_config=gc)
         S = ids.shape[1]
@@ -119,11 +129,23 @@ class GroupRollout:
         kl = per_token_kl(ref, lp)
         texts = self.decode(comp)
         completions = [[{"role": "assistant", "content": t}] for t in texts]
-        cols = {k: [v] * self.G for k, v in example.items() if k not in ("prompt", "completion")}
+        cols = {k: [v] * G_local for k, v in example.items() if k not in ("prompt", "completion")}
         rpf = torch.zeros(len(texts), len(self.reward_funcs), device=pc.device)
         for i, fn in enumerate(self.reward_funcs):
-            rpf[:, i] = torch.tensor(fn(prompts=[example.get("prompt")] * self.G, completions=completions, **cols),
+            rpf[:, i] = torch.tensor(fn(prompts=[example.get("prompt")] * G_local, completions=completions, **cols),
                                      dtype=torch.float32, device=pc.device)
+        if sharded:
+            # one exchange step: every rank ends up with the whole group in completion-index order (rank-major == index
+            # order).  Completions stop at different lengths on different ranks: right-pad to the longest.
+            T_all = int(o3v_dist.all_gather_records(torch.tensor([[float(comp.shape[1])]], device=pc.device)).max().item())
+            comp = o3v_dist.all_gather_padded(comp, T_all, self.pad)
+            cmask = o3v_dist.all_gather_padded(cmask, T_all, 0)
+            lp = o3v_dist.all_gather_padded(lp, T_all, 0.0)
+            ref = lp if self.ref_model is None else o3v_dist.all_gather_padded(ref, T_all, 0.0)
+            kl = per_token_kl(ref, lp)
+            rpf = o3v_dist.all_gather_records(rpf.contiguous())
+            texts = [t for part in o3v_dist.gather_objects(texts) for t in part]
+            pc = torch.cat([pc[:1, :S].expand(self.G, -1), comp], dim=1)
         rewards = rpf.sum(dim=1)
         adv, std = group_advantages(rewards, self.G)
         loss = gspo_loss(lp, lp, ref, adv, cmask, self.beta, self.el, self.eh, self.gspo)

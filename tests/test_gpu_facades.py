@@ -182,3 +182,58 @@ def test_group_rollout_step(need_gpu, golden_dir):
                image_grid_thw=torch.from_numpy(g["grid"]).repeat(G, 1)).logits
     ref_lp = torch.log_softmax(lg[:, :-1].float(), -1).gather(2, res.prompt_completion_ids[:, 1:, None].to(lg.device))[..., 0][:, S - 1:]
     assert torch.allclose(res.per_token_logps, ref_lp, atol=2e-4, rtol=0)
+
+
+def _gp_step(golden_dir, group_parallel, G=8, T=8):
+    from open_o3_video_amd import rewards, rollout
+    from open_o3_video_amd.hf_api import Qwen2_5_VLForConditionalGeneration
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    model = Qwen2_5_VLForConditionalGeneration.from_state_dict(cfg, fm.make_weights(cfg, 2))
+    tok = StubTokenizer(cfg)
+    gr = rollout.GroupRollout(model, [rewards.format_reward, lambda completions, **kw: [float(sum(map(ord, c[0]["content"])) % 7) for c in completions]],
+                              tok.batch_decode, eos_token_id=cfg["eos_token_id"], pad_token_id=cfg["pad_token_id"],
+                              num_generations=G, max_completion_length=T, group_parallel=group_parallel)
+    ids = torch.from_numpy(g["input_ids"])
+    res = gr.step(dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=torch.from_numpy(g["pixel_values"]),
+                       image_grid_thw=torch.from_numpy(g["grid"])), {"prompt": "p", "task": "temporal-spatial free-form QA"})
+    return dict(pc=res.prompt_completion_ids.cpu(), mask=res.completion_mask.cpu(), lp=res.per_token_logps.cpu(),
+                rewards=res.rewards.cpu(), adv=res.advantages.cpu(), loss=float(res.loss))
+
+
+def _gp_worker(rank, world, port, golden_dir, q):
+    import torch.distributed as td
+    from open_o3_video_amd import dist as od
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    od.init("gloo")                      # both ranks share the one GPU of the test box; the exchange runs over gloo
+    out = _gp_step(golden_dir, True)
+    q.put((rank, {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in out.items()}))
+    td.destroy_process_group()
+
+
+def test_group_parallel_rollout_two_ranks(need_gpu, golden_dir):
+    """BASELINE config #3 / SURVEY 8e partitioning B on the real engine: the G=8 completions of one prompt decoded as 2 x 4
+    rows by two ranks and all-gathered equal the group decoded by one rank -- same sampled ids (the sampler is keyed by the
+    global completion index), same rewards, advantages and loss."""
+    import socket
+    import torch.multiprocessing as mp
+    ref = _gp_step(golden_dir, False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gp_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in ps], key=lambda o: o[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m = ref["mask"].float()
+    for rank, out in outs:
+        assert out["pc"] == ref["pc"].tolist(), rank
+        assert out["mask"] == ref["mask"].tolist() and out["rewards"] == ref["rewards"].tolist()
+        assert torch.allclose(torch.tensor(out["lp"]) * m, ref["lp"] * m, atol=1e-5)
+        assert torch.allclose(torch.tensor(out["adv"]), ref["adv"], atol=1e-5) and abs(out["loss"] - ref["loss"]) < 1e-5

@@ -98,3 +98,81 @@ def test_two_process_gloo_world():
         assert metrics["completion_length"] == 5.0 and metrics["kl"] == pytest.approx(0.5)
         assert metrics["reward_std"] == pytest.approx(0.375)
         assert metrics["all_wrong"] == 0.0 and metrics["all_correct"] == 1.0
+
+
+# ---- group-parallel rollout (SURVEY 8e partitioning B / BASELINE config #3): G completions of one prompt over the ranks
+class _StubPolicy:
+    """Deterministic stand-in for the HF facade: completion `i` of a group depends only on its global index i."""
+    EOS, PAD = 9, 0
+
+    def generate(self, input_ids, attention_mask, pixel_values, image_grid_thw, generation_config):
+        gc = generation_config
+        G, off = gc.num_return_sequences, getattr(gc, "row_id_offset", 0)
+        rows = []
+        for g in range(G):
+            i = off + g
+            body = [10 + i + k for k in range(2 + (i * 3) % 5)] + [self.EOS]
+            rows.append(body)
+        T = min(gc.max_new_tokens, max(len(r) for r in rows))       # generation stops when every LOCAL row has finished
+        comp = torch.full((G, T), self.PAD, dtype=torch.int64)
+        for g, r in enumerate(rows):
+            comp[g, :min(T, len(r))] = torch.tensor(r[:T])
+        return torch.cat([torch.as_tensor(input_ids).expand(G, -1), comp], dim=1)
+
+    def completion_logps(self, prompt_ids, prompt_mask, completion_ids, pixel_values=None, image_grid_thw=None):
+        c = completion_ids.float()
+        return -(0.05 * c + 0.01 * torch.arange(c.shape[1])[None, :])
+
+
+def _group_step(group_parallel):
+    pol = _StubPolicy()
+    funcs = [lambda prompts, completions, **kw: [float(len(c[0]["content"])) for c in completions],
+             lambda prompts, completions, **kw: [float(c[0]["content"].count("1")) for c in completions]]
+    decode = lambda ids: [str([t for t in r.tolist() if t != pol.PAD]) for r in ids]     # skip_special_tokens drops the padding
+    gr = rollout.GroupRollout(pol, funcs, decode, eos_token_id=pol.EOS, pad_token_id=pol.PAD,
+                              num_generations=4, max_completion_length=12, group_parallel=group_parallel)
+    inputs = {"input_ids": torch.tensor([[5, 6, 7]]), "attention_mask": torch.ones(1, 3, dtype=torch.int64)}
+    res = gr.step(inputs, {"prompt": "p", "task": "t"})
+    return {k: getattr(res, k) for k in ("prompt_completion_ids", "completion_mask", "per_token_logps", "rewards_per_func",
+                                         "rewards", "advantages", "loss")} | {"completions": res.completions}
+
+
+def _group_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    od.init("gloo")
+    out = _group_step(group_parallel=True)
+    q.put((rank, {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in out.items()}))
+    torch.distributed.destroy_process_group()
+
+
+def test_group_parallel_rollout_equals_single_rank_group():
+    ref = _group_step(group_parallel=False)      # world size 1: the whole group on one rank
+    assert ref["prompt_completion_ids"].shape[0] == 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in ps], key=lambda o: o[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = ref["completion_mask"].float()
+    for rank, out in outs:
+        for k in ("prompt_completion_ids", "completion_mask", "rewards_per_func", "rewards", "completions"):
+            exp = ref[k].tolist() if torch.is_tensor(ref[k]) else ref[k]
+            assert out[k] == exp, (rank, k)
+        # positions after a row's EOS are masked out of every statistic; a rank never computes them past its own longest row
+        assert torch.allclose(torch.tensor(out["per_token_logps"]) * m, ref["per_token_logps"] * m, atol=1e-6)
+        assert torch.allclose(torch.tensor(out["advantages"]), ref["advantages"], atol=1e-6)
+        assert abs(out["loss"] - ref["loss"].item()) < 1e-6
+    with pytest.raises(ValueError):
+        # 3 completions cannot be split over 2 ranks -- checked before any collective; simulate a 2-rank world view
+        gr = rollout.GroupRollout(_StubPolicy(), [], lambda ids: [], 9, 0, num_generations=3, group_parallel=True)
+        orig = od.world
+        od.world = lambda: (0, 2)
+        try:
+            gr.step({"input_ids": torch.tensor([[1]]), "attention_mask": torch.ones(1, 1, dtype=torch.int64)}, {})
+        finally:
+            od.world = orig
