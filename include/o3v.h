@@ -104,7 +104,7 @@ int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const v
                            int M, int K, int ldx, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache,
                            int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);
 /* Decode nn.Linear with both weight images: W row-major [N,K] (M == 1) and Wp = the same weights in MFMA-fragment-major
- * order [N/16][K/32][64][8] (2 <= M <= 8, group rollout); norm_w (fused RMSNorm) and Wp may be NULL. */
+ * order [N/16][K/32][64][8] (4 <= M <= 16, group rollout / batched eval; 9..16 rows need Wp or an MFMA-shaped W); norm_w (fused RMSNorm) and Wp may be NULL. */
 int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* W, const void* Wp, const void* bias,
                       const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
                       o3v_stream_t stream);

@@ -871,7 +871,8 @@ extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* 
         prefix_len <= 0 || ctx <= prefix_len || ctx > Tmax || nsplit_prefix == 0)
         return O3V_ERR_ARG;
     const int n_rep = Hq / Hkv;
-    if (D != 128 || G * n_rep > 64) return O3V_ERR_SHAPE;
+    if (D != 128) return O3V_ERR_SHAPE;
+    if (nsplit_prefix > 0 && G * n_rep > 64) return O3V_ERR_SHAPE;  // the one-pass kernel holds the group in 64 MFMA columns
     if (nsplit_prefix < 0) {
         // shared-read form: the per-row kernel, with every row of a group reading the prefix from the group's first row
         const int ns = -nsplit_prefix;

@@ -200,7 +200,7 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
                             o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
-    if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
+    if (rows <= 8 || (rows <= 16 && d->lm_head_p))  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
         return o3v_linear_decode(x, d->final_norm, d->rms_eps, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows,
                                  d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
     TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
@@ -220,7 +220,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         !st->cur_tok || !st->finished || !st->out_ids || !st->part_o || !st->part_ml || !st->workspace)
         return O3V_ERR_ARG;
     const int B = st->B;
-    if (B <= 0 || B > 8 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew || st->S + st->Tnew > st->Tmax + 1)
+    if (B <= 0 || B > 16 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew || st->S + st->Tnew > st->Tmax + 1)
         return O3V_ERR_ARG;
     if (!st->sample_scratch) return O3V_ERR_ARG;
     const int H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter, V = d->vocab;

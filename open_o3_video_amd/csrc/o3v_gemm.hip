@@ -999,7 +999,7 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
                          float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
                          hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr) {
     if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
-    if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 8) return O3V_ERR_SHAPE;
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 16) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
@@ -1013,12 +1013,13 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
         a.packed = true;
     }
     if (M >= 4 && (K % 32) == 0 && (N % 16) == 0 && (epilogue != EPI_QKVROPE || (a.ra.D % 32) == 0) &&
-        (epilogue != EPI_SWIGLU || (N % 32) == 0) && (!a.packed || (N % 16 == 0)) && (!norm_w || (size_t)M * (K * 2 + 16) <= 120 * 1024)) {
+        (epilogue != EPI_SWIGLU || (N % 32) == 0) && (!a.packed || (N % 16 == 0)) && (!norm_w || (size_t)M * (K * 2 + 16) <= 144 * 1024)) {
         int rcm = launch_gemv_mfma(a, M);
         if (rcm != O3V_OK) return rcm;
         O3V_CHECK_LAUNCH();
         return O3V_OK;
     }
+    if (M > 8) return O3V_ERR_SHAPE;  // 9..16 rows exist only on the matrix-core path (one MFMA column block)
     a.W = (const bf16_t*)W;  // scalar path reads the row-major image
     a.packed = false;
     int rc;

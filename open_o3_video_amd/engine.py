@@ -43,6 +43,8 @@ class GenerateOutput:
 
 
 class O3VEngine:
+    MAX_ROWS = 16   # decode rows per call: the skinny MFMA GEMM multiplies 16 weight rows against up to 16 rows of x
+
     def __init__(self, cfg: O3VConfig, weights: DeviceWeights):
         if not torch.cuda.is_available():
             raise _lib.O3VError("O3VEngine needs a ROCm GPU (no CPU path)")
@@ -214,8 +216,9 @@ class O3VEngine:
             raise ValueError("only left padding is supported (padding_side='left', R:grpo_trainer.py:546)")
         G = int(num_return_sequences)
         B = B0 * G
-        if B > 8:
-            raise ValueError("at most 8 sequences per engine call (decode GEMV batch); shard larger batches")
+        if B > self.MAX_ROWS:
+            raise ValueError(f"at most {self.MAX_ROWS} sequences per engine call (one 16-column MFMA block in the decode linears); "
+                             "shard larger batches")
         pad_id = cfg.pad_token_id if pad_token_id is None else int(pad_token_id)
         T = int(max_new_tokens)
         tm = {}
@@ -295,13 +298,15 @@ class O3VEngine:
         # G * n_rep <= 64 query rows per kv head, prefix splits + own-key splits <= 64)
         n_rep = tc.num_attention_heads // tc.num_key_value_heads
         own_splits = (T + 127) // 128
-        group = G if (G > 1 and tc.head_dim == 128 and G * n_rep <= 64 and own_splits <= 32 and self.group_attention) else 0
+        group = G if (G > 1 and tc.head_dim == 128 and own_splits <= 32 and self.group_attention) else 0
         mode = self.group_attention_mode
         if mode == "auto":
             # measured, 7B dims, G=8 (tools/measure_configs.py rollout / rollout_eval): at S=4.5k the per-row kernel reading the
             # group leader's prefix through the shared L2 wins (4.56 vs 4.80 ms/step); at S=10k the one-pass group kernel
             # does (4.96 vs 5.08); without either 4.73 / 5.42
             mode = "kernel" if S >= 8192 else "shared_read"
+        if G * n_rep > 64:
+            mode = "shared_read"      # the one-pass kernel holds the group's query rows in 64 MFMA columns
         if group and mode == "shared_read":
             nsplit = -nsplit
         elif group:

@@ -187,10 +187,10 @@ class LLM:
                 vis, vkey = self._visual_tokens(frames)
                 grid = np.asarray([[1, frames.shape[2] // 14, frames.shape[3] // 14]] * frames.shape[0], dtype=np.int64)
             ro = RequestOutput(request_id=str(self._req), prompt=prompt, prompt_token_ids=ids)
-            # n samples of one prompt (self-consistency, R:eval/tts.py:47-123) run in groups of <= 8 decode rows; sample i is
+            # n samples of one prompt (self-consistency, R:eval/tts.py:47-123) run in groups of <= 16 decode rows; sample i is
             # keyed by (seed, i) whatever group it lands in, and groups after the first reuse the whole prompt K/V
-            for i0 in range(0, sp.n, 8):
-                g = min(8, sp.n - i0)
+            for i0 in range(0, sp.n, O3VEngine.MAX_ROWS):
+                g = min(O3VEngine.MAX_ROWS, sp.n - i0)
                 out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=sp.max_tokens,
                                            eos_token_ids=eos, pad_token_id=self.cfg.pad_token_id,
                                            repetition_penalty=sp.repetition_penalty, do_sample=not greedy,

@@ -136,11 +136,16 @@ def test_swiglu_gemm_and_gemv(dev, M, I, K):
         assert (out[:, I:] == 0).all()  # zero weight/bias pad rows -> silu(0)*0 = 0 exactly
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 12, 16])
 @pytest.mark.parametrize("N,K", [(64, 128), (4608, 3584), (3584, 18944), (1000, 896), (8192, 1280)])
 def test_gemv(dev, M, N, K):
-    from open_o3_video_amd import ops
+    from open_o3_video_amd import ops, _lib
     g = torch.Generator().manual_seed(M * 7 + N)
+    if M > 8 and N % 16:
+        # 9..16 rows exist only on the matrix-core path, which needs whole 16-row weight blocks: refused, not mis-computed
+        with pytest.raises(_lib.O3VError):
+            ops.gemm(torch.zeros(M, K, dtype=BF, device=dev), torch.zeros(N, K, dtype=BF, device=dev), force="gemv")
+        return
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
     bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
@@ -151,7 +156,7 @@ def test_gemv(dev, M, N, K):
         close_bf16(out, _epi_ref(acc, b, r, epi))
 
 
-@pytest.mark.parametrize("M", [1, 2, 4, 8])
+@pytest.mark.parametrize("M", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("N,K,epi_name", [(4608, 3584, "none"), (37888, 3584, "swiglu"), (152064, 3584, "none"),
                                           (512, 128, "none"), (2304, 896, "swiglu")])
 def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
@@ -175,7 +180,8 @@ def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
     close_bf16(out, ref, ulps=1, atol=1e-3, frac=0.9995)
 
 
-@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(1, 28, 4, 128, 3584), (3, 7, 1, 128, 896), (8, 4, 2, 32, 128)])
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(1, 28, 4, 128, 3584), (3, 7, 1, 128, 896), (8, 4, 2, 32, 128), (16, 28, 4, 128, 3584),
+                                           (11, 14, 2, 128, 896)])
 def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
     """Fully fused decode q/k/v projection == rmsnorm -> gemv(+bias) -> qkv_rope_cache (bit-identical outputs)."""
     import ctypes as C
@@ -218,7 +224,7 @@ def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
     assert (k2[:, :, :slot] == 0).all() and (k2[:, :, slot + 1:] == 0).all()
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 12, 16])
 @pytest.mark.parametrize("N,K,epi_name,norm", [(4608, 3584, "none", True), (37888, 3584, "swiglu", True), (3584, 18944, "res", False),
                                                (3584, 3584, "res", False), (152064, 3584, "none", True), (512, 128, "gelu", False),
                                                (2304, 896, "swiglu", True)])

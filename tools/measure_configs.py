@@ -41,7 +41,7 @@ def run(tag, frames_n, H, W, S_target, T, **kw):
 if "eval" in which:
     run("EVAL-RES 32x364x644 greedy B=1", 32, 364, 644, 10218, 256, repetition_penalty=1.05)
 if "rollout" in which:
-    for G in ([int(a[1:]) for a in sys.argv[1:] if a.startswith('G')] or (2, 4, 8)):
+    for G in ([int(a[1:]) for a in sys.argv[1:] if a.startswith('G')] or (2, 4, 8, 16)):
         run(f"rollout G={G} sampled top_p=0.95 (TRAIN-RES)", 32, 224, 420, 4490, 256, num_return_sequences=G, do_sample=True,
             top_p=0.95, temperature=1.0, seed=1)
 if "rollout_eval" in which:
