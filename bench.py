@@ -239,12 +239,12 @@ def main():
     # per-stage breakdown (one extra, untimed, synchronised step)
     stages = step(0, timings=True).timings
 
-    # extra (not `value`): throughput with 8 videos decoding together per GPU -- the eval path of the reference runs a
+    # extra (not `value`): throughput with 16 videos decoding together per GPU -- the eval path of the reference runs a
     # vLLM engine with max_num_seqs=5 (R:eval/models/model_vllm.py:23), i.e. it batches concurrent requests too.  Decode is
-    # weight-bandwidth-bound, so the 8 sequences share every streamed weight byte (MFMA skinny-GEMM path).
+    # weight-bandwidth-bound, so the 16 sequences share every streamed weight byte (MFMA skinny-GEMM path).
     batched = None
     if not args.no_batched:
-        NB = 8
+        NB = O3VEngine.MAX_ROWS
         vids8 = torch.randint(0, 256, (NB * args.frames, 3, Hres, Wres), generator=gen, dtype=torch.uint8, device=dev)
 
         def step8():
@@ -285,7 +285,7 @@ def main():
                                 "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None},
         }
         if batched:
-            rec["batched_8_videos"] = batched
+            rec["batched_videos"] = batched
         if roof:
             rec["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:

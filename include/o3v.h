@@ -99,7 +99,9 @@ int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void*
                        o3v_stream_t stream);
 
 /* Decode q/k/v projection fully fused: RMSNorm -> Linear(+bias) -> M-RoPE -> q to qout[M,Hq,D], k,v appended to the
- * cache [M,Hkv,Tmax,D] at `slot` (TF:733-736, :636-664); cos/sin row of sequence m = m*cs_stride_row + cs_off. */
+ * cache [M,Hkv,Tmax,D] at `slot` (TF:733-736, :636-664); cos/sin row of sequence m = m*cs_stride_row + cs_off.
+ * norm_w == NULL (M >= 4 only): X is already normalised (the batched decode runs o3v_rmsnorm apart, which frees the
+ * LDS the fused form stages x in and doubles the resident waves). */
 int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const void* W, const void* Wp, const void* bias,
                            int M, int K, int ldx, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache,
                            int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);

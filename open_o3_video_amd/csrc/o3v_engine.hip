@@ -200,7 +200,12 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
                             o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
-    if (rows <= 8 || (rows <= 16 && d->lm_head_p))  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
+    if (rows >= 8 && rows <= 16 && d->lm_head_p) {  // batched decode: norm apart, LDS-free matrix-core linear
+        TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
+        return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
+                                 d->vocab, 0, O3V_EPI_NONE, s);
+    }
+    if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
         return o3v_linear_decode(x, d->final_norm, d->rms_eps, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows,
                                  d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
     TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
@@ -241,6 +246,11 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     }
     int ev_i = 0;
     const size_t o_bytes = (size_t)H * QD * 2, gu_bytes = (size_t)2 * I * H * 2;
+    // B >= 4 rows run on the matrix-core linears, which stage the normalised x of a fused RMSNorm in LDS (57 KB at B=8, 115 KB
+    // at B=16: two blocks, then one, per CU).  With a separate 3 us norm launch the linears are LDS-free: gate/up 54 -> 44 us
+    // at B=8, 75 -> 50 us at B=16 (profiles/r01_m8_linear.txt).  Whole step, 7B: B=4 3.56 -> 3.61 ms (worse: two more
+    // launches per layer), B=8 4.04 -> 3.97, B=16 5.63 -> 5.25: taken from B=8 on.
+    const bool norm_apart = B >= 8;
     for (int i = 0; i < n_steps; ++i) {
         const int step = step0 + i;
         if (st->do_sample)
@@ -258,8 +268,14 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
-            TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
-                                       kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            if (norm_apart) {
+                TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+                TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc,
+                                           vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            } else {
+                TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT,
+                                           w.q, kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            }
             if (st->side_stream && st->prefetch_bytes) {
                 hipEvent_t ev = ev_ring[ev_i++ & 7];
                 if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
@@ -278,8 +294,14 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                     st->Tmax, st->nsplit, scale, s));
             TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H,
                                   O3V_EPI_RESIDUAL, s));
-            TRY(o3v_linear_decode(st->x, lw.ln2, d->rms_eps, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
-                                  O3V_EPI_SWIGLU, s));
+            if (norm_apart) {
+                TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
+                TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
+                                      O3V_EPI_SWIGLU, s));
+            } else {
+                TRY(o3v_linear_decode(st->x, lw.ln2, d->rms_eps, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
+                                      O3V_EPI_SWIGLU, s));
+            }
             TRY(o3v_linear_decode(w.mlp, nullptr, 0.f, lw.down_w, lw.down_wp, nullptr, st->x, st->x, B, H, I, I, H, H,
                                   O3V_EPI_RESIDUAL, s));
         }

@@ -966,7 +966,9 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
 static int launch_gemv_mfma(const GemvArgs& a, int M) {
     const int groups = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 32 : (a.N + 15) / 16;
     // wave tasks = row groups x K slices: aim at >= 2048 waves (8 per CU) so enough weight loads are in flight
-    int ks = groups >= 2048 ? 1 : (groups >= 1024 ? 2 : 4);
+    // (A/B in profiles/r01_m8_linear.txt: the LDS-free form -- x already normalised, fragments from L2 -- keeps 4-way
+    // K splits profitable up to 2048 groups; with x staged in LDS two blocks per CU are the limit and 2-way is better)
+    int ks = groups >= 2048 ? 1 : ((groups >= 1024 && a.norm_w) ? 2 : 4);
 #ifdef O3V_TUNE
     if (g_mt_ks) ks = g_mt_ks;
 #endif
@@ -986,9 +988,7 @@ static int launch_gemv_mfma(const GemvArgs& a, int M) {
         case EPI_RESIDUAL: O3V_MM(EPI_RESIDUAL);
         case EPI_GELU: O3V_MM(EPI_GELU);
         case EPI_SWIGLU: O3V_MM(EPI_SWIGLU);
-        case EPI_QKVROPE:
-            if (!a.norm_w) return O3V_ERR_ARG;
-            O3V_MK(EPI_QKVROPE, true);
+        case EPI_QKVROPE: O3V_MM(EPI_QKVROPE);
         default: return O3V_ERR_ARG;
     }
 #undef O3V_MM
@@ -1072,9 +1072,9 @@ extern "C" int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float e
                                       const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT,
                                       void* qout, void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax,
                                       int cs_stride_row, int cs_off, hipStream_t stream) {
-    if (!norm_w || !cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 ||
-        (D & 1))
+    if (!cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 || (D & 1))
         return O3V_ERR_ARG;
+    if (!norm_w && M < 4) return O3V_ERR_ARG;  // un-fused norm (X already normalised) exists on the matrix-core path only
     RopeArgs ra{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache,
                 slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
     return gemv_dispatch(X, W, bias, nullptr, nullptr, norm_w, eps, M, (Hq + 2 * Hkv) * D, K, ldx, K, 0, 0, EPI_QKVROPE, stream,

@@ -300,17 +300,20 @@ class O3VEngine:
         own_splits = (T + 127) // 128
         group = G if (G > 1 and tc.head_dim == 128 and own_splits <= 32 and self.group_attention) else 0
         mode = self.group_attention_mode
-        if mode == "auto":
-            # measured, 7B dims, G=8 (tools/measure_configs.py rollout / rollout_eval): at S=4.5k the per-row kernel reading the
-            # group leader's prefix through the shared L2 wins (4.56 vs 4.80 ms/step); at S=10k the one-pass group kernel
-            # does (4.96 vs 5.08); without either 4.73 / 5.42
-            mode = "kernel" if S >= 8192 else "shared_read"
-        if G * n_rep > 64:
-            mode = "shared_read"      # the one-pass kernel holds the group's query rows in 64 MFMA columns
-        if group and mode == "shared_read":
-            nsplit = -nsplit
-        elif group:
-            nsplit = max(1, min(64 - own_splits, (S + 127) // 128))
+        if group:
+            # the one-pass kernel holds a group's query rows in 64 MFMA columns: larger groups run as sub-groups of the
+            # largest divisor of G that fits (every row carries its own copy of the prompt K/V, so any row can lead)
+            sub = max(d for d in range(1, G + 1) if G % d == 0 and d * n_rep <= 64)
+            if mode == "auto":
+                # measured, 7B dims (tools/measure_configs.py rollout / rollout_eval): G=8, S=4.5k: the per-row kernel reading
+                # the leader's prefix through the shared L2 wins (4.56 vs 4.80 ms/step; neither: 4.73); S=10k: the one-pass
+                # group kernel does (4.96 vs 5.08; neither: 5.42); G=16: shared-read is L2-bound (39 us/layer)
+                mode = "kernel" if (S >= 8192 or B >= 12) and sub > 1 else "shared_read"
+            if mode == "kernel" and sub > 1:
+                group = sub
+                nsplit = max(1, min(64 - own_splits, (S + 127) // 128))
+            else:
+                nsplit = -nsplit
         part_o = torch.empty(n_rep_total * 64 * tc.head_dim, dtype=torch.float32, device=self.dev)
         part_ml = torch.empty(n_rep_total * 64 * 2, dtype=torch.float32, device=self.dev)
         scratch = torch.empty((B, _lib.SAMPLE_SCRATCH_FLOATS if do_sample else 256), dtype=torch.float32, device=self.dev)

@@ -26,11 +26,11 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 H, I = 3584, 18944
 shapes = {"gate_up": (2 * I, H, 3, True), "down": (H, I, 1, False), "o_proj": (H, H, 1, False), "qkv": (4608, H, 0, True),
-          "lm_head": (152064, H, 0, True)}
+          "lm_head": (152064, H, 0, True), "gate_up (norm apart)": (2 * I, H, 3, False), "lm_head (norm apart)": (152064, H, 0, False)}
 g = torch.Generator(device=dev).manual_seed(0)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for name, (N, K, epi, norm) in shapes.items():
-    nl = 4 if name == "lm_head" else 28
+    nl = 4 if name.startswith("lm_head") else 28
     ws = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).normal_(0, 0.02, generator=g) for _ in range(nl)]
     wps = [pack_mfma_fragments(w) for w in ws]
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -56,6 +56,6 @@ for name, (N, K, epi, norm) in shapes.items():
             res_t[v].append(e0.elapsed_time(e1) * 1e3 / nl)
     med = {v: sorted(t)[1] for v, t in res_t.items()}
     best = min(med, key=med.get)
-    print(f"M={M} {name:8s} {N * K * 2 / 1e6:7.1f} MB  " + "  ".join(f"KS{v[0]}U{v[1]}:{t:6.1f}" for v, t in med.items()) +
+    print(f"M={M} {name:22s} {N * K * 2 / 1e6:7.1f} MB  " + "  ".join(f"KS{v[0]}U{v[1]}:{t:6.1f}" for v, t in med.items()) +
           f"   best KS{best[0]} U{best[1]} = {N * K * 2 / med[best] / 1e6:.2f} TB/s", flush=True)
     del ws, wps
