@@ -221,6 +221,8 @@ class O3VEngine:
                              "shard larger batches")
         pad_id = cfg.pad_token_id if pad_token_id is None else int(pad_token_id)
         T = int(max_new_tokens)
+        if T <= 0:
+            raise ValueError(f"`max_new_tokens` must be greater than 0, but is {T}.")   # GenerationConfig.validate's rule
         tm = {}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if sync_timings else None
 

@@ -283,3 +283,43 @@ def test_completion_logps_shared_prompt(need_gpu):
     assert torch.equal(again, ours)
     one = eng.completion_logps(ids, comp[:, :1], frames=frames).cpu()
     assert (one[:, 0] - ours[:, 0]).abs().max().item() < 1e-6
+
+
+def test_generate_edge_cases(need_gpu):
+    """Degenerate shapes of the generate call: zero (refused) and one new token, a one-token text-only prompt, 16 left-padded rows of
+    different lengths in one call (each equal to its own single-row run), every row hitting EOS on its first token."""
+    cfg = fm.tiny_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 11))
+    fr = fm.make_frames(2, 56, 84, seed=4)
+    _, grid = eng.pixels_from_frames(fr)
+    ids = fm.make_prompt(cfg, [tuple(r) for r in grid.tolist()], seed=4)
+    S = len(ids)
+    with pytest.raises(ValueError):
+        eng.generate([ids], None, frames=fr, max_new_tokens=0)               # refused like GenerationConfig.validate does
+    one = eng.generate([ids], None, frames=fr, max_new_tokens=1).sequences
+    five = eng.generate([ids], None, frames=fr, max_new_tokens=5).sequences
+    assert one.shape == (1, S + 1) and torch.equal(one[0], five[0, :S + 1])
+    # text only, a single token
+    t1 = eng.generate([[7]], None, max_new_tokens=4).sequences
+    assert t1.shape == (1, 5) and t1[0, 0].item() == 7
+    # 16 rows, text-only prompts of lengths 1..16, left padded
+    pad = cfg["pad_token_id"]
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(10, 200, n).tolist() for n in range(1, 17)]
+    L = 16
+    rows = [[pad] * (L - len(p)) + p for p in prompts]
+    mask = [[0] * (L - len(p)) + [1] * len(p) for p in prompts]
+    both = eng.generate(rows, mask, max_new_tokens=6).sequences.cpu().numpy()
+    assert both.shape == (16, L + 6)
+    for i in (0, 1, 7, 15):
+        solo = eng.generate([prompts[i]], None, max_new_tokens=6).sequences.cpu().numpy()[0]
+        assert np.array_equal(both[i, L:], solo[len(prompts[i]):]), i
+    # every row ends on its first generated token: one step, EOS kept, nothing after it
+    first = both[:, L]
+    out = eng.generate(rows, mask, max_new_tokens=6, eos_token_ids=sorted(set(first.tolist())), pad_token_id=pad,
+                       steps_per_sync=1)
+    assert out.n_steps == 1 and np.array_equal(out.sequences.cpu().numpy()[:, L], first)
+    with pytest.raises(ValueError):
+        eng.generate([[1, 2]] * 17, None, max_new_tokens=1)                 # more rows than one engine call takes
+    with pytest.raises(ValueError):
+        eng.generate([ids], None, frames=fr[:1], max_new_tokens=1)          # fewer frames than image placeholders
