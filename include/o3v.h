@@ -82,6 +82,8 @@ int o3v_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, o3v_stre
 /* nn.Linear: out[M,N] = epi(A[M,K] . W[N,K]^T + bias); K % 64 == 0.  MFMA path (ViT, merger, prefill). */
 int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
+/* Tile choice of o3v_gemm_bf16: 0 = per shape (default), 128 or 256 = force that kernel (tests and A/B measurements). */
+int o3v_gemm_set_tile(int tile);
 /* o3v_gemm_bf16 for row counts too small to fill the chip with 128x128 output tiles (a prompt suffix behind a cached
  * prefix: 9..128 rows): K split over `splits` blocks per tile, fp32 partials in `workspace` (splits*M*N floats), reduced
  * in split order.  Epilogues NONE / RESIDUAL / GELU. */

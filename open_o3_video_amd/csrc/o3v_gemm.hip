@@ -47,6 +47,143 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
     }
 }
 
+// Epilogue of one wave's 64x64 fp32 sub-tile whose top-left output element is (mrow0, ncol0); `et` is the wave's own
+// 64 x 68 float staging area in LDS.  C/D map of 16x16x32: col = lane&15, row = (lane>>4)*4 + reg.
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const f32x4 (&acc)[4][4], float* et, int lane, int mrow0, int ncol0, int M, int N,
+                                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                              bf16_t* __restrict__ out, int ldo, int ldr) {
+    const int fr = lane & 15, fg = lane >> 4;
+    // Fast path: the wave's 64x64 fp32 sub-tile goes through LDS (row stride 68 floats: the two 32-lane halves of a
+    // ds_write_b32 land on disjoint banks) and comes back row-wise, 8 consecutive columns per lane, so bias / residual are
+    // 16-byte loads and every output row segment is a 16-byte store of a full 128-byte line per 8 lanes.
+    const bool vec_ok = ((N & 7) == 0) && ((ldo & 7) == 0) && (EPI != EPI_RESIDUAL || (ldr & 7) == 0);
+    if (vec_ok) {
+        constexpr int ES = 68;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) et[(i * 16 + fg * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
+        // same wave writes and reads its own region; LDS operations of a wave complete in order
+        if (EPI == EPI_SWIGLU) {
+            const int no0 = (ncol0) >> 1;  // first output column of this wave (32 per wave)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + (lane >> 2), oc = (lane & 3) * 8;
+                const int m = mrow0 + row, no = no0 + oc;
+                if (m >= M || no >= (N >> 1)) continue;
+                const int gcol = (oc >> 4) * 32 + (oc & 15);  // gate columns in the tile; up = +16
+                const float* gp = et + row * ES + gcol;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(gp + 16), u1 = *reinterpret_cast<const f32x4*>(gp + 20);
+                float gb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (bias) {
+                    const int ng = ncol0 + gcol;
+                    const u32x4 bg = *reinterpret_cast<const u32x4*>(bias + ng), bu = *reinterpret_cast<const u32x4*>(bias + ng + 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gb[2 * q] = bf_lo(bg[q]);
+                        gb[2 * q + 1] = bf_hi(bg[q]);
+                        ub[2 * q] = bf_lo(bu[q]);
+                        ub[2 * q + 1] = bf_hi(bu[q]);
+                    }
+                }
+                float o8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float gv = rbf((q < 4 ? g0[q] : g1[q - 4]) + gb[q]);
+                    const float uv = rbf((q < 4 ? u0[q] : u1[q - 4]) + ub[q]);
+                    o8[q] = rbf(silu_f(gv)) * uv;
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(o8[2 * q], o8[2 * q + 1]);
+                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + no) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                const int m = mrow0 + row, n = ncol0 + c8;
+                if (m >= M || n >= N) continue;
+                const float* ep = et + row * ES + c8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep), v1 = *reinterpret_cast<const f32x4*>(ep + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (bias) {
+                    const u32x4 bb = *reinterpret_cast<const u32x4*>(bias + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] += bf_lo(bb[q]);
+                        v[2 * q + 1] += bf_hi(bb[q]);
+                    }
+                }
+                if (EPI == EPI_RESIDUAL) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldr + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = rbf(v[2 * q]) + bf_lo(rr[q]);
+                        v[2 * q + 1] = rbf(v[2 * q + 1]) + bf_hi(rr[q]);
+                    }
+                }
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf_f(rbf(v[q]));
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
+                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = pk;
+            }
+        }
+        return;
+    }
+    if (EPI == EPI_SWIGLU) {
+        // W rows interleaved in 16-row groups: even groups = gate rows, odd groups = up rows of the same
+        // 16 output columns (host packs them), so acc[i][2jj] / acc[i][2jj+1] meet in one lane.
+        const int No = N >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int ng = ncol0 + jj * 32 + fr;  // gate row index in the packed weight
+                const int no = ((ncol0) >> 1) + jj * 16 + fr;
+                if (no >= No) continue;
+                const float bg = bias ? bf2f(bias[ng]) : 0.f;
+                const float bu = bias ? bf2f(bias[ng + 16]) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow0 + i * 16 + fg * 4 + r;
+                    if (m >= M) continue;
+                    const float g = rbf(acc[i][2 * jj][r] + bg);
+                    const float u = rbf(acc[i][2 * jj + 1][r] + bu);
+                    out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ncol0 + j * 16 + fr;
+                if (n >= N) continue;
+                const float bv = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow0 + i * 16 + fg * 4 + r;
+                    if (m >= M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
+                    if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+                    out[(size_t)m * ldo + n] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
@@ -131,136 +268,103 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
             }
         return;
     }
-    // Fast path: the wave's 64x64 fp32 sub-tile goes through LDS (row stride 68 floats: the two 32-lane halves of a
-    // ds_write_b32 land on disjoint banks) and comes back row-wise, 8 consecutive columns per lane, so bias / residual are
-    // 16-byte loads and every output row segment is a 16-byte store of a full 128-byte line per 8 lanes.
-    const bool vec_ok = ((N & 7) == 0) && ((ldo & 7) == 0) && (EPI != EPI_RESIDUAL || (ldr & 7) == 0);
-    if (vec_ok) {
-        constexpr int ES = 68;
-        float* et = reinterpret_cast<float*>(smem) + wave * 64 * ES;  // main loop ended with a barrier: tiles are dead
+    // main loop ended with a barrier: the tiles are dead, every wave stages its sub-tile in its own 64 x 68 float region
+    wave_epilogue<EPI>(acc, reinterpret_cast<float*>(smem) + wave * 64 * 68, lane, m0 + wm * 64, n0 + wn * 64, M, N, bias, res, out,
+                       ldo, ldr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4), each wave a 128 x 64 sub-tile (8 x 4 MFMA blocks).  The 128-tile kernel above is
+// LDS-bound: per 32-deep k-slice a wave reads 8 KiB of fragments for 16 MFMAs and the block stages 32 KiB per k-step.
+// Here a wave reads 12 KiB for 32 MFMAs and the block stages 64 KiB for four times the work: ~2/3 of the LDS bytes per
+// FLOP at the same two waves per SIMD.  One block per CU (128 KiB of tiles); the launcher uses it for the big prefill
+// GEMMs whose 256-tile grid still fills the chip evenly.
+// ------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256;
+constexpr int TILE2_BYTES = BM2 * BK * 2;  // 32 KiB per operand tile
+
+__device__ __forceinline__ void stage_tile256(const bf16_t* __restrict__ g, int ld, int row0, int rows_valid, int k0,
+                                              char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int instr = wave * 4 + i;  // 32 wave-instructions of 1 KiB per tile, 4 per wave
+        const int row = instr * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = row0 + row;
+        grow = grow < rows_valid ? grow : rows_valid - 1;
+        const bf16_t* src = g + (size_t)grow * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + instr * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                           bf16_t* __restrict__ out, int M, int N, int K, int lda, int ldw,
+                                                           int ldo, int ldr, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K]; epilogue: 8 x 64 x 68 floats
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM2, n0 = tn * BM2;
+
+    f32x4 acc[2][4][4];  // [row half][i][j]: rows wm*128 + half*64 + i*16, cols wn*64 + j*16
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) et[(i * 16 + fg * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
-        // same wave writes and reads its own region; LDS operations of a wave complete in order
-        const int mrow0 = m0 + wm * 64;
-        if (EPI == EPI_SWIGLU) {
-            const int no0 = (n0 + wn * 64) >> 1;  // first output column of this wave (32 per wave)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 16 + (lane >> 2), oc = (lane & 3) * 8;
-                const int m = mrow0 + row, no = no0 + oc;
-                if (m >= M || no >= (N >> 1)) continue;
-                const int gcol = (oc >> 4) * 32 + (oc & 15);  // gate columns in the tile; up = +16
-                const float* gp = et + row * ES + gcol;
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(gp + 16), u1 = *reinterpret_cast<const f32x4*>(gp + 20);
-                float gb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (bias) {
-                    const int ng = n0 + wn * 64 + gcol;
-                    const u32x4 bg = *reinterpret_cast<const u32x4*>(bias + ng), bu = *reinterpret_cast<const u32x4*>(bias + ng + 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        gb[2 * q] = bf_lo(bg[q]);
-                        gb[2 * q + 1] = bf_hi(bg[q]);
-                        ub[2 * q] = bf_lo(bu[q]);
-                        ub[2 * q + 1] = bf_hi(bu[q]);
-                    }
-                }
-                float o8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float gv = rbf((q < 4 ? g0[q] : g1[q - 4]) + gb[q]);
-                    const float uv = rbf((q < 4 ? u0[q] : u1[q - 4]) + ub[q]);
-                    o8[q] = rbf(silu_f(gv)) * uv;
-                }
-                u32x4 pk;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(o8[2 * q], o8[2 * q + 1]);
-                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + no) = pk;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-                const int m = mrow0 + row, n = n0 + wn * 64 + c8;
-                if (m >= M || n >= N) continue;
-                const float* ep = et + row * ES + c8;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep), v1 = *reinterpret_cast<const f32x4*>(ep + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (bias) {
-                    const u32x4 bb = *reinterpret_cast<const u32x4*>(bias + n);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[2 * q] += bf_lo(bb[q]);
-                        v[2 * q + 1] += bf_hi(bb[q]);
-                    }
-                }
-                if (EPI == EPI_RESIDUAL) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldr + n);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[2 * q] = rbf(v[2 * q]) + bf_lo(rr[q]);
-                        v[2 * q + 1] = rbf(v[2 * q + 1]) + bf_hi(rr[q]);
-                    }
-                }
-                if (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf_f(rbf(v[q]));
-                }
-                u32x4 pk;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
-                *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = pk;
-            }
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    const int fr = lane & 15, fg = lane >> 4;
+    stage_tile256(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile256(W, ldw, n0, N, 0, smem + TILE2_BYTES, wave, lane);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        char* cur = smem + (t & 1) * 2 * TILE2_BYTES;
+        char* nxt = smem + ((t + 1) & 1) * 2 * TILE2_BYTES;
+        if (t + 1 < nk) {
+            stage_tile256(A, lda, m0, M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile256(W, ldw, n0, N, (t + 1) * BK, nxt + TILE2_BYTES, wave, lane);
         }
-        return;
-    }
-    if (EPI == EPI_SWIGLU) {
-        // W rows interleaved in 16-row groups: even groups = gate rows, odd groups = up rows of the same
-        // 16 output columns (host packs them), so acc[i][2jj] / acc[i][2jj+1] meet in one lane.
-        const int No = N >> 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int ng = n0 + wn * 64 + jj * 32 + fr;  // gate row index in the packed weight
-                const int no = ((n0 + wn * 64) >> 1) + jj * 16 + fr;
-                if (no >= No) continue;
-                const float bg = bias ? bf2f(bias[ng]) : 0.f;
-                const float bu = bias ? bf2f(bias[ng + 16]) : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
-                    if (m >= M) continue;
-                    const float g = rbf(acc[i][2 * jj][r] + bg);
-                    const float u = rbf(acc[i][2 * jj + 1][r] + bu);
-                    out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fr;
-                if (n >= N) continue;
-                const float bv = bias ? bf2f(bias[n]) : 0.f;
+                const int row = wn * 64 + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(cur + TILE2_BYTES + swz_off(row, ks * 4 + fg));
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
-                    if (m >= M) continue;
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
-                    if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
-                    out[(size_t)m * ldo + n] = f2bf(v);
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wm * 128 + h * 64 + i * 16 + fr;
+                    af[i] = *reinterpret_cast<const bf16x8*>(cur + swz_off(row, ks * 4 + fg));
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[h][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h][i][j], 0, 0, 0);
             }
         }
+        __syncthreads();
     }
+    float* et = reinterpret_cast<float*>(smem) + wave * 64 * 68;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        wave_epilogue<EPI>(acc[h], et, lane, m0 + wm * 128 + h * 64, n0 + wn * 64, M, N, bias, res, out, ldo, ldr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -889,6 +993,15 @@ extern "C" int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bi
     return O3V_OK;
 }
 
+static int g_gemm_tile = 0;  // 0: choose per shape; 128 / 256: force (tests, A/B runs)
+extern "C" int o3v_gemm_set_tile(int tile) {
+    g_gemm_tile = (tile == 128 || tile == 256) ? tile : 0;
+    return O3V_OK;
+}
+
+// fraction of the chip's block slots a grid of `tiles` blocks keeps busy over its ceil(tiles/slots) rounds
+static inline float fill_eff(int tiles, int slots) { return (float)tiles / (float)(((tiles + slots - 1) / slots) * slots); }
+
 extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                              int lda, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {
     if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
@@ -897,6 +1010,29 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int t2m = (M + BM2 - 1) / BM2, t2n = (N + BM2 - 1) / BM2;
+    // 256-tiles: one block per CU (256 slots), more padding at ragged edges; 128-tiles: two blocks per CU (512 slots)
+    constexpr float O3V_GEMM256_GAIN = 1.3f;  // full-grid speed ratio of the two kernels (profiles/r01_gemm_tile_ab.txt)
+    const float use128 = fill_eff(tiles_m * tiles_n, 512) * ((float)M * N / ((float)tiles_m * BM * (float)tiles_n * BN));
+    const float use256 = O3V_GEMM256_GAIN * fill_eff(t2m * t2n, 256) * ((float)M * N / ((float)t2m * BM2 * (float)t2n * BM2));
+    const bool big = g_gemm_tile ? g_gemm_tile == 256 : (M >= 1024 && N >= 1024 && use256 > use128);
+    if (big) {
+        dim3 grid(t2m * t2n), block(512);
+        const size_t shmem = 8 * 64 * 68 * 4;  // max(2 stages x (A + B) = 128 KiB, epilogue staging 8 waves x 64 x 68 f32)
+#define O3V_GM2(E)                                                                                                     \
+    O3V_KLAUNCH((gemm256_bf16_kernel<E>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)W,               \
+                (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, lda, ldw, ldo, ldr, t2m, t2n)
+        switch (epilogue) {
+            case EPI_NONE: O3V_GM2(EPI_NONE); break;
+            case EPI_RESIDUAL: O3V_GM2(EPI_RESIDUAL); break;
+            case EPI_GELU: O3V_GM2(EPI_GELU); break;
+            case EPI_SWIGLU: O3V_GM2(EPI_SWIGLU); break;
+            default: return O3V_ERR_ARG;
+        }
+#undef O3V_GM2
+        O3V_CHECK_LAUNCH();
+        return O3V_OK;
+    }
     dim3 grid(tiles_m * tiles_n), block(256);
     const size_t shmem = 4 * 64 * 68 * 4;  // max(2 stages x (A+B) = 64 KiB, epilogue staging 4 waves x 64 x 68 f32)
 #define O3V_GM(E)                                                                                                       \

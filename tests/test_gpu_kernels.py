@@ -109,6 +109,43 @@ def test_gemm_splitk(dev, M, N, K, splits):
         close_bf16(out, ops.gemm(a, w, b, r, epi, force="gemm").float(), ulps=1, atol=1e-3, frac=0.999)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (700, 1280, 192), (515, 3456, 1280), (1030, 520, 128), (300, 4608, 3584)])
+def test_gemm_256_tile_kernel(dev, M, N, K):
+    """The 8-wave 256x256 kernel (forced here; the launcher picks it for the big prefill shapes): every epilogue, ragged M
+    and N edges, against the fp32 reference and bit-identical to the 128-tile kernel (same k order per output element)."""
+    from open_o3_video_amd import ops, _lib
+    from open_o3_video_amd.weights import pack_gate_up
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    acc = a.float() @ w.float().t()
+    cases = [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, bias, res), (ops.EPI_GELU, None, None)]
+    try:
+        outs = {}
+        for tile in (256, 128):
+            _lib.call("o3v_gemm_set_tile", tile)
+            outs[tile] = [ops.gemm(a, w, b, r, epi, force="gemm") for epi, b, r in cases]
+        for o256, o128, (epi, b, r) in zip(outs[256], outs[128], cases):
+            close_bf16(o256, _epi_ref(acc, b, r, epi))
+            assert torch.equal(o256, o128)
+        if N % 32 == 0:
+            I = N // 2
+            wg, wu = w[:I].contiguous(), w[I:].contiguous()
+            packed = pack_gate_up(wg, wu, I)
+            sw = []
+            for tile in (256, 128):
+                _lib.call("o3v_gemm_set_tile", tile)
+                sw.append(ops.gemm(a, packed, None, None, ops.EPI_SWIGLU, force="gemm"))
+            assert torch.equal(sw[0], sw[1])
+            gv = rb(a.float() @ wg.float().t())
+            uv = rb(a.float() @ wu.float().t())
+            close_bf16(sw[0], rb(torch.nn.functional.silu(gv)) * uv)
+    finally:
+        _lib.call("o3v_gemm_set_tile", 0)
+
+
 def _swiglu_case(dev, M, I, K, ipad, seed):
     from open_o3_video_amd import ops
     from open_o3_video_amd.weights import pack_gate_up

@@ -18,6 +18,7 @@ shapes = [  # name, M, N(weight rows), K, epi, bias
     ("vit qkv", 15360, 3840, 1280, 0, True), ("vit proj+res", 15360, 1280, 1280, 1, True),
     ("vit gate/up swiglu", 15360, 6912, 1280, 3, True), ("vit down+res", 15360, 1280, 3456, 1, True),
     ("square 4096", 4096, 4096, 4096, 0, False), ("square 8192", 8192, 8192, 8192, 0, False),
+    ("llm gate/up S=10218", 10218, 37888, 3584, 3, False), ("llm down S=10218", 10218, 3584, 18944, 1, False),
 ]
 g = torch.Generator(device=dev).manual_seed(0)
 tot_t, tot_f = 0.0, 0.0
@@ -33,14 +34,18 @@ for name, M, N, K, epi, hb in shapes:
     def run():
         for i in range(nrep):
             _lib.call("o3v_gemm_bf16", P(a[i]), P(w[i]), P(bias), P(res), P(out), M, N, K, K, K, No, No, epi, st)
-    run()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); run(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / nrep)
-    t = sorted(ts)[2]
     fl = 2.0 * M * N * K
-    print(f"{name:22s} M={M:6d} N={N:6d} K={K:6d}  {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s", flush=True)
+    line = f"{name:22s} M={M:6d} N={N:6d} K={K:6d} "
+    for tile in (128, 256, 0):   # forced 128-tile kernel, forced 256-tile kernel, the launcher's own choice
+        _lib.call("o3v_gemm_set_tile", tile)
+        run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / nrep)
+        t = sorted(ts)[2]
+        line += f" | {'auto' if tile == 0 else tile}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TFLOP/s"
+    print(line, flush=True)
     del a, w
