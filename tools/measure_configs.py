@@ -139,8 +139,8 @@ if "logps" in which:
 
 if "tts16" in which:
     # BASELINE config #5 (test-time scaling, N=16 chains of one 32-frame question, R:eval/test/test_videomme.py:129-226):
-    # two groups of 8 sampled rows; the second group reuses the whole prompt K/V.  256 tokens per chain.  The reference
-    # runs 16 sequential generate calls, each with its own ViT pass and prefill.
+    # one group of 16 sampled rows behind one ViT pass and one prefill.  256 tokens per chain.  The reference runs 16
+    # sequential generate calls, each with its own ViT pass and prefill.
     from open_o3_video_amd import tts
     tpf = (224 // 28) * (420 // 28)
     ids = build_prompt(cfg, 32, tpf, 4490)
@@ -155,10 +155,8 @@ if "tts16" in which:
         px, grid = eng.pixels_from_frames(frames)
         vis = eng.vit_forward(px, grid)
         reused = 0
-        for i0 in (0, 8):
-            out = eng.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, num_return_sequences=8,
-                               row_ids=list(range(i0, i0 + 8)), prefix_key="q", **kw)
-            reused += out.timings["prefix_tokens_reused"]
+        out = eng.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, num_return_sequences=16, prefix_key="q", **kw)
+        reused += out.timings["prefix_tokens_reused"]
         claims = [{"obj": "o", "box_xyxy": [20 + 3 * i, 10 + 2 * i, 200 + 5 * i, 150 + 3 * i], "t_sec": float(i)} for i in range(10)]
         crops = tts.extract_and_crop(frames, 1.0, claims)
         torch.cuda.synchronize()
