@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--res", default="train", choices=["train", "eval"])
     ap.add_argument("--model", default="7b", choices=["7b", "3b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched", action="store_true", help="skip the extra 8-videos-per-step throughput measurement")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra 16-videos-per-step throughput measurement")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
