@@ -101,3 +101,58 @@ def test_fullsize_properties(eng7b):
     px2, grid2 = eng.pixels_from_frames(frames[:6][perm])
     v2 = eng.vit_forward(px2, grid2).view(6, tpf, -1)
     assert torch.equal(v2, v1[perm])
+
+
+def test_fullsize_reuse_paths(eng7b):
+    """The reuse paths at the same full size, as properties:
+      P5  prompt-prefix K/V reuse: a prompt whose first 4400 tokens were cached by another question gives the first token
+          of the cold run (when its margin is safe) and teacher-forced suffix logits within the path-to-path tolerance;
+      P6  a 16-row completion group (matrix-core linears at 16 rows, sub-grouped group attention) has identical greedy rows;
+      P7  shared-prompt completion log-probs == the full-sequence formulation;
+      P8  the 256-tile and the 128-tile GEMM give bit-identical prefill logits."""
+    from open_o3_video_amd import _lib
+    eng, cfg = eng7b, eng7b.cfg
+    F, H, W = 32, 224, 420
+    tpf = (H // 28) * (W // 28)
+    ids = _prompt(cfg, F, tpf)
+    S = len(ids)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    cold = eng.generate([ids], None, frames=frames, max_new_tokens=6)
+    # P5
+    other = list(ids)
+    other[-15] = ids[-15] + 1
+    eng.drop_prefix_cache()
+    eng.generate([other], None, frames=frames, max_new_tokens=1, prefix_key="vid")
+    warm = eng.generate([ids], None, frames=frames, max_new_tokens=6, prefix_key="vid")
+    assert warm.timings["prefix_tokens_reused"] == S - 15
+    if cold.margins[0, 0] > 0.6:
+        assert warm.sequences[0, S] == cold.sequences[0, S]
+    m = min(cold.n_steps, warm.n_steps)
+    differ = (warm.sequences[0, S:S + m] != cold.sequences[0, S:S + m]).nonzero()
+    if differ.numel():      # the two runs may part ways only at a token whose top-1/top-2 margin is within the logit noise
+        j = int(differ[0])
+        assert min(cold.margins[0, j].item(), warm.margins[0, j].item()) <= 0.6, f"prefix reuse changed a safe-margin token at step {j}"
+    eng.drop_prefix_cache()
+    # P6
+    grp = eng.generate([ids], None, frames=frames, max_new_tokens=6, num_return_sequences=16).sequences
+    assert grp.shape[0] == 16 and all(torch.equal(grp[i], grp[0]) for i in range(16))
+    assert torch.equal(grp[0, :S + 1], cold.sequences[0, :S + 1])
+    # P7
+    comp = torch.randint(1000, 150000, (4, 12), generator=torch.Generator().manual_seed(1))
+    lp = eng.completion_logps(ids, comp, frames=frames).cpu()
+    seq0 = torch.cat([torch.tensor(ids), comp[2]])[None]
+    full = eng.per_token_logps(eng.forward_logits(seq0.numpy(), None, frames=frames), seq0).cpu()[0, S - 1:]
+    d = (lp[2] - full).abs()
+    print(f"P7: shared-prompt vs full-sequence log-probs: max|diff| {d.max():.4f}, mean|diff| {d.mean():.4f} (values ~ {full.mean():.2f})")
+    # same envelope as P2: with random 28-layer weights two correct summation orders differ by up to ~0.8 in a logit
+    assert d.max().item() < 1.0 and d.mean().item() < 0.3
+    # P8
+    try:
+        _lib.call("o3v_gemm_set_tile", 128)
+        l128 = eng.forward_logits(np.asarray([ids]), None, frames=frames)[0, -1]
+        _lib.call("o3v_gemm_set_tile", 0)
+        lauto = eng.forward_logits(np.asarray([ids]), None, frames=frames)[0, -1]
+    finally:
+        _lib.call("o3v_gemm_set_tile", 0)
+    assert torch.equal(l128, lauto)
