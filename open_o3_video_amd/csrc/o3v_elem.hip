@@ -17,8 +17,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     if (row >= rows) return;
     const int nch = cols >> 3;  // 16-byte chunks per row
     const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * ld_in);
-    uint4 v[MAXCH];
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    uint4 v[MAXCH], wv[MAXCH];
     float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {  // the weight chunks ride along with the row: one memory latency instead of two
+        int c = lane + i * 64;
+        if (c < nch) wv[i] = wr[c];
+    }
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         int c = lane + i * 64;
@@ -35,15 +41,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
     ss = wave_sum(ss);
     const float rstd = 1.0f / sqrtf(ss / (float)cols + eps);
-    const uint4* wr = reinterpret_cast<const uint4*>(w);
     uint4* orow = reinterpret_cast<uint4*>(out + (size_t)row * ld_out);
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         int c = lane + i * 64;
         if (c < nch) {
-            uint4 wv = wr[c];
             const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv[i]);
             uint4 o;
             uint32_t* po = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
