@@ -79,11 +79,38 @@ def gather_objects(obj) -> list:
     return out
 
 
+_queue_serial = 0
+
+
+def dynamic_indices(n_items: int):
+    """Work queue over the process group's key-value store: every rank draws the next unclaimed item index with one
+    atomic `add` (a few bytes over the rendezvous TCP store, no collective, no data-path traffic).  Completion lengths vary
+    by more than 10x between videos, so static chunks leave ranks idle at the end of an eval; with a queue the
+    imbalance is bounded by one item."""
+    global _queue_serial
+    r, w = world()
+    if w == 1:
+        yield from range(n_items)
+        return
+    store = dist.distributed_c10d._get_default_store()
+    key = f"o3v/queue/{_queue_serial}"      # same serial on every rank: calls are made in the same order everywhere
+    _queue_serial += 1
+    while True:
+        i = store.add(key, 1) - 1
+        if i >= n_items:
+            return
+        yield i
+
+
 def run_data_parallel(items: Sequence, fn: Callable, policy: str = "contiguous") -> List:
     """Evaluate fn(item) over this rank's shard and return ALL results in the original item order on every rank
-    (the eval harness' results_list + reorder-by-original_index, R:eval/test/test_vstar_multi_images.py:661-689)."""
+    (the eval harness' results_list + reorder-by-original_index, R:eval/test/test_vstar_multi_images.py:661-689).
+    policy: "contiguous" (the reference's static chunks), "strided", or "dynamic" (work queue, see dynamic_indices)."""
     r, w = world()
-    idx = contiguous_chunk(len(items), r, w) if policy == "contiguous" else strided_chunk(len(items), r, w)
+    if policy == "dynamic":
+        idx = dynamic_indices(len(items))
+    else:
+        idx = contiguous_chunk(len(items), r, w) if policy == "contiguous" else strided_chunk(len(items), r, w)
     mine = [(i, fn(items[i])) for i in idx]
     merged = [p for part in gather_objects(mine) for p in part]
     merged.sort(key=lambda p: p[0])

@@ -68,6 +68,17 @@ def _worker(rank, world, port, q):
     # sharded eval: every rank gets all results in order
     res = od.run_data_parallel(list(range(11)), lambda x: x * x + rank * 0, policy="contiguous")
     res2 = od.run_data_parallel(list(range(11)), lambda x: -x, policy="strided")
+    # dynamic queue: rank 1 is slow, so rank 0 must end up with most of the items; twice in a row (fresh queue each time)
+    import time as _t
+    taken = []
+
+    def slow(x):
+        taken.append(x)
+        _t.sleep(0.05 if rank == 1 else 0.002)
+        return x + 100
+    res3 = od.run_data_parallel(list(range(40)), slow, policy="dynamic")
+    n_first = len(taken)
+    res4 = od.run_data_parallel(list(range(7)), lambda x: x * 3, policy="dynamic")
     # rollout metrics record: rank r contributes rewards r+1
     G, nf = 4, 7
     rr = rollout.RolloutResult(None, None, torch.ones(G, 5, dtype=torch.int32), None, None, torch.full((G, 5), 0.5),
@@ -75,7 +86,7 @@ def _worker(rank, world, port, q):
     gr = rollout.GroupRollout(None, [lambda **k: 0] * nf, None, 0, 0, num_generations=G)
     metrics = gr.gather_metrics(rr, torch.full((G,), 0.25 * (rank + 1)))
     gathered = od.all_gather_records(torch.full((2, 3), float(rank)))
-    q.put((rank, res, res2, metrics, gathered.tolist()))
+    q.put((rank, res, res2, metrics, gathered.tolist(), res3, res4, n_first))
     torch.distributed.destroy_process_group()
 
 
@@ -90,7 +101,9 @@ def test_two_process_gloo_world():
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, res, res2, metrics, gathered in outs:
+    assert outs[0][7] + outs[1][7] == 40 and outs[0][7] > outs[1][7] + 10      # every item once; the fast rank took most
+    for rank, res, res2, metrics, gathered, res3, res4, n_first in outs:
+        assert res3 == [x + 100 for x in range(40)] and res4 == [x * 3 for x in range(7)]
         assert res == [x * x for x in range(11)]
         assert res2 == [-x for x in range(11)]
         assert gathered == [[0.0] * 3] * 2 + [[1.0] * 3] * 2
