@@ -194,7 +194,7 @@ class O3VEngine:
                  max_new_tokens=16, eos_token_ids: Sequence[int] = (), pad_token_id: Optional[int] = None,
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
-                 vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 32, return_margins: bool = True,
+                 vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 16, return_margins: bool = True,
                  sync_timings: bool = False, prefix_key=None) -> GenerateOutput:
         """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
         completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out.
