@@ -60,6 +60,7 @@ class O3VEngine:
         self.clip_mean = (C.c_float * 3)(*CLIP_MEAN)   # host arrays (read by the launcher, passed by value)
         self.clip_std = (C.c_float * 3)(*CLIP_STD)
         self._vit_plan_cache = {}
+        self._prefix = {}   # prefix_key -> {"ids", "k", "v"}: prompt K/V kept for reuse (see generate(prefix_key=...))
         # side stream for the weight prefetch beside the decode attention (O3V_PREFETCH_MB=0 disables)
         import os
         self.prefetch_bytes = int(float(os.environ.get("O3V_PREFETCH_MB", "0")) * 1e6)
@@ -365,7 +366,7 @@ class O3VEngine:
     def _prefix_lookup(self, key, ids_row: np.ndarray) -> int:
         """Tokens of `ids_row` whose K/V are cached under `key`: the longest common prefix, capped at S-1 so the
         last prompt token is always run (its hidden state feeds the first logits)."""
-        ent = getattr(self, "_prefix", {}).get(key)
+        ent = self._prefix.get(key)
         if ent is None:
             return 0
         old = ent["ids"]
@@ -374,8 +375,6 @@ class O3VEngine:
         return int(neq[0]) if neq.size else int(n)
 
     def _prefix_store(self, key, ids_row: np.ndarray, kc0, vc0):
-        if not hasattr(self, "_prefix"):
-            self._prefix = {}
         self._prefix.pop(key, None)
         while len(self._prefix) >= self.PREFIX_ENTRIES:
             self._prefix.pop(next(iter(self._prefix)))
