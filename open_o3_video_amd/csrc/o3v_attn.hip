@@ -19,6 +19,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 struct TileDesc {  // 8 ints, built on the host (open_o3_video_amd/indexing.py)
     int q_row0;      // first query token (row of Q / O)
@@ -48,15 +49,21 @@ struct AttnCfg {
 // where every K fragment read and every transposed V read from LDS feeds two MFMAs instead of one -- the kernel is
 // LDS-bandwidth-bound at RQ = 1).
 template <int D, int RQ>
-__global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          const TileDesc* __restrict__ tiles, long q_ts, long k_ts,
                                                          long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
                                                          int n_rep, float scale_log2e) {
     using C = AttnCfg<D>;
+    // head_dim 128: K/V tiles go global -> LDS by DMA (global_load_lds, no registers), double buffered, so the loads of
+    // tile kt+1 run under the MFMAs of tile kt and a tile costs one barrier instead of two.  Rows are 256 B = 16 chunks
+    // with no padding (a DMA instruction fills 1 KiB of consecutive LDS); the chunk a lane fetches is XOR-swizzled with the
+    // row number instead, which keeps both the K fragment reads and the transposed V reads conflict-free.
+    constexpr bool DMA = (D == 128);
+    constexpr int STAGE = 2 * 64 * 256;  // K tile + V tile of one DMA stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
-    char* Vl = smem + C::K_BYTES;
+    char* Vl = smem + (DMA ? 64 * 256 : C::K_BYTES);
 
     const TileDesc td = tiles[blockIdx.x];
     const int h = blockIdx.y, hk = h / n_rep;
@@ -140,10 +147,28 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
         }
     };
     if (SPLIT && kt_lo < kt_hi) load_tile(kt_lo);
+    auto dma_tile = [&](int kt, char* stage) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int instr = wave * 4 + j;              // 16 instructions of 4 rows per tile, 4 per wave
+            const int row = instr * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);      // logical 16-byte chunk stored at slot (lane & 15) of the row
+            int kr = kt * 64 + row;
+            kr = kr < td.k_len ? kr : td.k_len - 1;
+            __builtin_amdgcn_global_load_lds(Kb + (size_t)kr * k_ts + c * 8, (lds_void_t*)(stage + instr * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Vb + (size_t)kr * v_ts + c * 8, (lds_void_t*)(stage + 64 * 256 + instr * 1024), 16, 0, 0);
+        }
+    };
+    if (DMA && kt_lo < kt_hi) dma_tile(kt_lo, smem);
 
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        if (SPLIT) {
+        __syncthreads();  // DMA: tile kt has landed (vmcnt(0) + barrier) and tile kt-1 is fully consumed
+        if (DMA) {
+            const int st = (kt - kt_lo) & 1;
+            Kl = smem + st * STAGE;
+            Vl = Kl + 64 * 256;
+            if (kt + 1 < kt_hi) dma_tile(kt + 1, smem + (st ^ 1) * STAGE);
+        } else if (SPLIT) {
             store_tile();
         } else {
             // ---- stage K (zero padded to DPAD) and V tiles through registers
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
                 *reinterpret_cast<uint4*>(Vl + row * C::VSTRIDE + ch * 16) = v;
             }
         }
-        __syncthreads();
+        if (!DMA) __syncthreads();
         if (SPLIT && kt + 1 < kt_hi) load_tile(kt + 1);
         // wave-level skip: with a causal mask a wave whose rows all precede this key tile has nothing to do
         if (td.causal_off >= 0 && kt * 64 > td.causal_off + (wave * RQ + RQ) * 16 - 1) continue;
@@ -177,7 +202,8 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const bf16x8 kf =
-                    *reinterpret_cast<const bf16x8*>(Kl + (kb * 16 + fr) * C::KSTRIDE + (ks * 32 + fg * 8) * 2);
+                    DMA ? *reinterpret_cast<const bf16x8*>(Kl + (kb * 16 + fr) * 256 + (((ks * 4 + fg) ^ fr) << 4))
+                        : *reinterpret_cast<const bf16x8*>(Kl + (kb * 16 + fr) * C::KSTRIDE + (ks * 32 + fg * 8) * 2);
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) s[rq][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][ks], s[rq][kb], 0, 0, 0);
             }
@@ -235,12 +261,16 @@ __global__ __launch_bounds__(256) void attn_tiles_kernel(const bf16_t* __restric
         const int tq = fr >> 2, tp = fr & 3;  // tr-read: lane 4q+p of the 16-lane group addresses row q, cols 4p..4p+3
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const char* r0 = Vl + (kk * 32 + fg * 4 + tq) * C::VSTRIDE + tp * 8;
-            const char* r1 = r0 + 16 * C::VSTRIDE;
+            // DMA layout: row * 256 + ((chunk ^ (row & 15)) << 4) + half * 8 with chunk = 2 db + (tp >> 1), half = tp & 1;
+            // rows of r0 and r1 differ by 16, so they share (row & 15)
+            const int vrow = kk * 32 + fg * 4 + tq, vx = vrow & 15;
+            const char* r0 = DMA ? Vl + vrow * 256 + (tp & 1) * 8 : Vl + vrow * C::VSTRIDE + tp * 8;
+            const char* r1 = r0 + 16 * (DMA ? 256 : C::VSTRIDE);
 #pragma unroll
             for (int db = 0; db < C::DB; ++db) {
-                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + db * 32));
-                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + db * 32));
+                const int voff = DMA ? (((2 * db + (tp >> 1)) ^ vx) << 4) : db * 32;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + voff));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + voff));
                 const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) o[rq][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[rq][kk], o[rq][db], 0, 0, 0);
@@ -802,7 +832,7 @@ extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void*
     const float sl2 = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, Hq), block(256);
 #define O3V_AT1(DD, RQ)                                                                                               \
-    O3V_KLAUNCH((attn_tiles_kernel<DD, RQ>), grid, block, AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES, stream,      \
+    O3V_KLAUNCH((attn_tiles_kernel<DD, RQ>), grid, block, (DD == 128 ? 4 * 64 * 256 : AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES), stream, \
                        (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, (const TileDesc*)tiles, q_ts, \
                        k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2)
 #define O3V_AT(DD)                       \
