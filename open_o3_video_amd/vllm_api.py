@@ -87,6 +87,7 @@ class LLM:
         if tokenizer is None:
             raise ValueError("a tokenizer is required (encode / decode / convert_tokens_to_ids)")
         self.engine, self.tokenizer = engine, tokenizer
+        self.max_num_seqs = int(max_num_seqs)   # requests of one generate() call decoded together (<= O3VEngine.MAX_ROWS)
         self.cfg = engine.cfg
         self.max_model_len = max_model_len
         self.limit_mm = dict(limit_mm_per_prompt or {})
@@ -171,7 +172,14 @@ class LLM:
         sp = sampling_params or SamplingParams()
         if isinstance(inputs, dict):
             inputs = [inputs]
-        results = []
+        greedy = sp.temperature == 0.0
+        stop = list(sp.stop_token_ids) if sp.stop_token_ids else []
+        eos = stop + ([self.cfg.eos_token_id] if self.cfg.eos_token_id is not None else [])
+        common = dict(max_new_tokens=sp.max_tokens, eos_token_ids=eos, pad_token_id=self.cfg.pad_token_id,
+                      repetition_penalty=sp.repetition_penalty, do_sample=not greedy,
+                      temperature=1.0 if greedy else sp.temperature, top_p=1.0 if greedy else sp.top_p, return_margins=False)
+        # ---- per request: frames -> (cached) visual tokens, prompt -> ids
+        prepared = []
         for req in inputs:
             prompt = req["prompt"] if isinstance(req, dict) else str(req)
             frames = self._frames(req.get("multi_modal_data") if isinstance(req, dict) else None)
@@ -179,34 +187,56 @@ class LLM:
             ids = self._tokenize(prompt, 0 if frames is None else frames.shape[0], tpf)
             if len(ids) + sp.max_tokens > self.max_model_len:
                 raise ValueError(f"prompt ({len(ids)}) + max_tokens ({sp.max_tokens}) exceeds max_model_len {self.max_model_len}")
-            greedy = sp.temperature == 0.0
-            stop = list(sp.stop_token_ids) if sp.stop_token_ids else []
-            eos = stop + ([self.cfg.eos_token_id] if self.cfg.eos_token_id is not None else [])
             vis, grid, vkey = None, None, ("text-only",)
             if frames is not None:
                 vis, vkey = self._visual_tokens(frames)
                 grid = np.asarray([[1, frames.shape[2] // 14, frames.shape[3] // 14]] * frames.shape[0], dtype=np.int64)
+            prepared.append((prompt, ids, vis, grid, vkey))
+
+        def finish(ro, index, row, n_prompt):
+            toks = row[n_prompt:].tolist()
+            reason = "length"
+            for j, t in enumerate(toks):
+                if t in eos:
+                    toks, reason = toks[:j], "stop"   # vLLM drops the stop token from the text
+                    break
+            ro.outputs.append(CompletionOutput(index, self.tokenizer.decode(toks, skip_special_tokens=True), toks, reason))
+
+        results = []
+        if len(prepared) > 1 and sp.n == 1 and self.max_num_seqs > 1:
+            # several requests in one call (vLLM batches them, R:eval/models/model_vllm.py:23 max_num_seqs): decode up to
+            # max_num_seqs of them together, left padded, every streamed weight byte shared by the rows of the step
+            rows_per_call = min(self.max_num_seqs, O3VEngine.MAX_ROWS)
+            for c0 in range(0, len(prepared), rows_per_call):
+                chunk = prepared[c0:c0 + rows_per_call]
+                L = max(len(p[1]) for p in chunk)
+                pad = self.cfg.pad_token_id
+                rows = [[pad] * (L - len(p[1])) + p[1] for p in chunk]
+                mask = [[0] * (L - len(p[1])) + [1] * len(p[1]) for p in chunk]
+                vis_parts = [p[2] for p in chunk if p[2] is not None]
+                grid_parts = [p[3] for p in chunk if p[3] is not None]
+                out = self.engine.generate(rows, mask, vis_embeds=torch.cat(vis_parts) if vis_parts else None,
+                                           image_grid_thw=np.concatenate(grid_parts) if grid_parts else None,
+                                           row_ids=[self._req + i for i in range(len(chunk))],
+                                           seed=0 if sp.seed is None else sp.seed, **common)
+                for i, p in enumerate(chunk):
+                    ro = RequestOutput(request_id=str(self._req), prompt=p[0], prompt_token_ids=p[1])
+                    finish(ro, 0, out.sequences[i], L)
+                    results.append(ro)
+                    self._req += 1
+            return results
+        for prompt, ids, vis, grid, vkey in prepared:
             ro = RequestOutput(request_id=str(self._req), prompt=prompt, prompt_token_ids=ids)
             # n samples of one prompt (self-consistency, R:eval/tts.py:47-123) run in groups of <= 16 decode rows; sample i is
             # keyed by (seed, i) whatever group it lands in, and groups after the first reuse the whole prompt K/V
             for i0 in range(0, sp.n, O3VEngine.MAX_ROWS):
                 g = min(O3VEngine.MAX_ROWS, sp.n - i0)
-                out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, max_new_tokens=sp.max_tokens,
-                                           eos_token_ids=eos, pad_token_id=self.cfg.pad_token_id,
-                                           repetition_penalty=sp.repetition_penalty, do_sample=not greedy,
-                                           temperature=1.0 if greedy else sp.temperature, top_p=1.0 if greedy else sp.top_p,
-                                           num_return_sequences=g, row_ids=list(range(i0, i0 + g)),
-                                           seed=self._req if sp.seed is None else sp.seed, return_margins=False,
-                                           prefix_key=vkey if self.enable_prefix_caching else None)
+                out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, num_return_sequences=g,
+                                           row_ids=list(range(i0, i0 + g)), seed=self._req if sp.seed is None else sp.seed,
+                                           prefix_key=vkey if self.enable_prefix_caching else None, **common)
                 self.prefix_tokens_reused += int(out.timings.get("prefix_tokens_reused", 0))
                 for i in range(g):
-                    toks = out.sequences[i, len(ids):].tolist()
-                    reason = "length"
-                    for j, t in enumerate(toks):
-                        if t in eos:
-                            toks, reason = toks[:j], "stop"   # vLLM drops the stop token from the text
-                            break
-                    ro.outputs.append(CompletionOutput(i0 + i, self.tokenizer.decode(toks, skip_special_tokens=True), toks, reason))
+                    finish(ro, i0 + i, out.sequences[i], len(ids))
             results.append(ro)
             self._req += 1
         return results

@@ -148,6 +148,17 @@ def test_vllm_facade(need_gpu, golden_dir):
     o7 = llm.generate({"prompt": prompt, "multi_modal_data": {"image": frames}}, sp4)[0].outputs
     assert [o.index for o in o6] == list(range(10)) and len({tuple(o.token_ids) for o in o6}) > 1
     assert all(o6[i].token_ids == o7[i].token_ids for i in range(4))
+    # several requests in one call are decoded together (left padded, one weight stream for all rows): same greedy tokens as
+    # one at a time; a second, shorter prompt over other frames rides along
+    fr2 = fm.make_frames(2, 56, 84, seed=21)
+    prompt2 = " ".join(["w7", "<|vision_start|>", "<|image_pad|>", "<|vision_end|>"] * 2 + ["w33", "w34"])
+    solo2 = llm.generate({"prompt": prompt2, "multi_modal_data": {"image": fr2}}, sp)[0].outputs[0].token_ids
+    both = llm.generate([{"prompt": prompt, "multi_modal_data": {"image": frames}},
+                         {"prompt": prompt2, "multi_modal_data": {"image": fr2}},
+                         {"prompt": prompt, "multi_modal_data": {"image": frames}}], sp)
+    assert [len(b.outputs) for b in both] == [1, 1, 1] and both[0].prompt_token_ids == ids
+    assert both[0].outputs[0].token_ids == exp and both[2].outputs[0].token_ids == exp and both[1].outputs[0].token_ids == solo2
+    assert [b.request_id for b in both] == [str(int(both[0].request_id) + i) for i in range(3)]
     # switching the reuse off gives the same greedy tokens
     llm2 = LLM(engine=eng, tokenizer=StubTokenizer(cfg), limit_mm_per_prompt={"image": 32}, max_model_len=4096,
                enable_prefix_caching=False)
