@@ -560,9 +560,8 @@ __global__ __launch_bounds__(256) void sample_greedy_partial_kernel(const bf16_t
     const int i0 = nb * per, i1 = (i0 + per < V) ? i0 + per : V;
     float best = -INFINITY, second = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-        float s = bf2f(lr[i]);
-        if (rep_penalty != 1.0f && sr[i]) s = (s < 0.f) ? s * rep_penalty : s / rep_penalty;
+    auto visit = [&](int i, float s, unsigned seen_byte) {
+        if (rep_penalty != 1.0f && seen_byte) s = (s < 0.f) ? s * rep_penalty : s / rep_penalty;
         if (s > best) {
             second = best;
             best = s;
@@ -570,6 +569,21 @@ __global__ __launch_bounds__(256) void sample_greedy_partial_kernel(const bf16_t
         } else if (s > second) {
             second = s;
         }
+    };
+    const bool vec = ((per & 7) == 0) && ((V & 7) == 0) && ((ldl & 7) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(seen) & 7) == 0);
+    if (vec) {
+        // 16 bytes of logits + 8 bytes of the seen map per lane and trip: the slice is two trips instead of ten dependent ones
+        for (int g = (i0 >> 3) + threadIdx.x; g < (i1 >> 3); g += 256) {
+            const uint4 lv = *reinterpret_cast<const uint4*>(lr + g * 8);
+            const uint2 sv = *reinterpret_cast<const uint2*>(sr + g * 8);
+            const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)   // ascending index inside the lane: the first maximum wins, like torch.argmax
+                visit(g * 8 + k, (k & 1) ? bf_hi(lw[k >> 1]) : bf_lo(lw[k >> 1]), ((k < 4 ? sv.x : sv.y) >> (8 * (k & 3))) & 0xffu);
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) visit(i, bf2f(lr[i]), sr[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
