@@ -140,6 +140,10 @@ int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* o
 int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
                       const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
                       int out_stride, float* scratch /* f32[B*256] */, o3v_stream_t stream);
+/* o3v_sample_greedy + embed_tokens of the chosen token (TF:1206-1207) in the same launch: x_out bf16 [B, hidden] */
+int o3v_sample_greedy_embed(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
+                            const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
+                            int out_stride, float* scratch, const void* embed, void* x_out, int hidden, o3v_stream_t stream);
 /* temperature + top-p + multinomial (TF:logits_process.py:301-303, :527-539; utils.py:2921-2923), counter-based RNG
  * keyed by (seed, row_id[b], step) so a completion does not depend on which rank/batch slot produced it */
 int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* chosen_logprob,

@@ -614,7 +614,9 @@ __global__ __launch_bounds__(64) void sample_greedy_final_kernel(const float* __
                                                                  int* __restrict__ cur_tok, int* __restrict__ finished,
                                                                  int* __restrict__ out_ids, float* __restrict__ margins,
                                                                  const int* __restrict__ eos_ids, int n_eos, int pad_id,
-                                                                 int V, int step, int out_stride) {
+                                                                 int V, int step, int out_stride,
+                                                                 const uint4* __restrict__ embed, uint4* __restrict__ x_out,
+                                                                 int hidden) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* p = part + ((size_t)b * GREEDY_NB + lane) * 4;
     float best = -INFINITY, second = -INFINITY;
@@ -640,23 +642,49 @@ __global__ __launch_bounds__(64) void sample_greedy_final_kernel(const float* __
         cur_tok[b] = tok;
         out_ids[(size_t)b * out_stride + step] = tok;
         if (margins) margins[(size_t)b * out_stride + step] = best - second;
+        bi = tok;
+    }
+    if (embed) {  // the next decode forward starts from this token's embedding row: gather it here, one launch less per step
+        const int tok = __shfl(bi, 0, 64);
+        const int cpr = hidden >> 3;
+        const uint4* src = embed + (size_t)(tok >= 0 ? tok : 0) * cpr;
+        for (int c = lane; c < cpr; c += 64) x_out[(size_t)b * cpr + c] = src[c];
     }
 }
 
 // scratch: f32 [B, 64, 4] partials
-extern "C" int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
-                                 const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty,
-                                 int step, int out_stride, float* scratch, hipStream_t stream) {
+static int sample_greedy_impl(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
+                              const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
+                              int out_stride, float* scratch, const void* embed, void* x_out, int hidden, hipStream_t stream) {
     if (!logits || !seen || !cur_tok || !finished || !out_ids || !scratch || B < 0 || V <= 0 || step < 0 ||
         step >= out_stride)
         return O3V_ERR_ARG;
+    if (embed && (!x_out || hidden <= 0 || (hidden & 7))) return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
     O3V_KLAUNCH(sample_greedy_partial_kernel, dim3(GREEDY_NB, B), dim3(256), 0, stream, (const bf16_t*)logits,
                 (const uint8_t*)seen, scratch, V, ldl, rep_penalty);
     O3V_KLAUNCH(sample_greedy_final_kernel, dim3(B), dim3(64), 0, stream, scratch, (uint8_t*)seen, cur_tok, finished, out_ids,
-                margins, eos_ids, n_eos, pad_id, V, step, out_stride);
+                margins, eos_ids, n_eos, pad_id, V, step, out_stride, (const uint4*)embed, (uint4*)x_out, hidden);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
+                                 const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty,
+                                 int step, int out_stride, float* scratch, hipStream_t stream) {
+    return sample_greedy_impl(logits, seen, cur_tok, finished, out_ids, margins, eos_ids, n_eos, pad_id, B, V, ldl, rep_penalty,
+                              step, out_stride, scratch, nullptr, nullptr, 0, stream);
+}
+
+// The same, and the chosen token's embedding row goes to x_out[b] (bf16 [B, hidden]) -- what the next decode forward
+// (TF:1206-1207 embed_tokens of the new token) starts from.
+extern "C" int o3v_sample_greedy_embed(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids,
+                                       float* margins, const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl,
+                                       float rep_penalty, int step, int out_stride, float* scratch, const void* embed,
+                                       void* x_out, int hidden, hipStream_t stream) {
+    if (!embed) return O3V_ERR_ARG;
+    return sample_greedy_impl(logits, seen, cur_tok, finished, out_ids, margins, eos_ids, n_eos, pad_id, B, V, ldl, rep_penalty,
+                              step, out_stride, scratch, embed, x_out, hidden, stream);
 }
 
 // mark prompt ids as seen (repetition penalty covers prompt + generated, TF:logits_process.py:404-414)

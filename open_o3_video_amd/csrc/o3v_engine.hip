@@ -257,13 +257,14 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_sample_top_p(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, st->temperature, st->top_p, st->seed,
                                  st->row_id, step, st->Tnew, st->sample_scratch, s));
-        else
-            TRY(o3v_sample_greedy(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
-                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, st->sample_scratch, s));
+        else  // greedy: the chosen token's embedding row is gathered by the sampler's last stage
+            TRY(o3v_sample_greedy_embed(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
+                                        st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, st->sample_scratch,
+                                        d->embed, st->x, H, s));
         if (skip_last_forward && i == n_steps - 1) break;
         if (st->S + step >= st->Tmax) return O3V_ERR_ARG;
         // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
-        TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
+        if (st->do_sample) TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
         for (int l = 0; l < d->layers; ++l) {
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
