@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
 
     // weight loads of one trip (U steps x R rows, 16 B per lane each): issued as early as possible
     u32x4 wv[U][R];
+    u32x4 xg[NORM ? 1 : U][NORM ? 1 : M];  // un-normalised x comes from global memory (L2): fetched one trip ahead, with the weights
     auto load_w = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -455,6 +456,10 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             for (int r = 0; r < R; ++r) {
                 wv[u][r] = __builtin_nontemporal_load(wp[r] + cc);
                 if (!in) wv[u][r] = (u32x4){0, 0, 0, 0};
+            }
+            if (!NORM) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) xg[u][m] = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
             }
         }
     };
@@ -557,8 +562,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             const int cc = c < c_end ? c : c_begin;  // out-of-range lanes meet zeroed weights
 #pragma unroll
             for (int m = 0; m < M; ++m)
-                xv[u][m] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + (size_t)cc * 8) * 2)
-                                : *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
+                xv[u][m] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + (size_t)cc * 8) * 2) : xg[NORM ? 0 : u][NORM ? 0 : m];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
