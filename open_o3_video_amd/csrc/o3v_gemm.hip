@@ -435,6 +435,28 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         const int rr = rows[r] < N ? rows[r] : N - 1;  // tail rows re-read a valid row, never stored
         wp[r] = reinterpret_cast<const u32x4*>(W + (size_t)rr * ldw);
     }
+    // Epilogue operands (bias, residual, rotary cos/sin) are requested here, a whole kernel ahead of their use: these
+    // kernels live for 7-25 us, and a dependent L2 round trip at the tail is 5-10 % of that.
+    float e_bias[R], e_res[EPI == EPI_RESIDUAL ? R : 1][EPI == EPI_RESIDUAL ? M : 1], e_cos[EPI == EPI_QKVROPE ? M : 1],
+        e_sin[EPI == EPI_QKVROPE ? M : 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rr = rows[r] < N ? rows[r] : N - 1;
+        e_bias[r] = bias ? bf2f(bias[rr]) : 0.f;
+        if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) e_res[r][m] = bf2f(res[(size_t)m * ldr + rr]);
+        }
+    }
+    if (EPI == EPI_QKVROPE) {
+        const int jj = (rows[0] < N ? rows[0] : 0) % ra.D;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + jj;
+            e_cos[m] = bf2f(ra.cosT[cs]);
+            e_sin[m] = bf2f(ra.sinT[cs]);
+        }
+    }
     // K-slice in whole 64-chunk steps
     const int steps = (nch + 63) >> 6;
     const int sps = (steps + KS - 1) / KS;
@@ -601,7 +623,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     if (EPI == EPI_QKVROPE) {
         if (rows[0] >= N) return;
         const int half = ra.D >> 1, head = rows[0] / ra.D, j = rows[0] % ra.D;
-        const float b0 = bias ? bf2f(bias[rows[0]]) : 0.f, b1 = bias ? bf2f(bias[rows[R - 1]]) : 0.f;
+        const float b0 = e_bias[0], b1 = e_bias[R - 1];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const float v0 = rbf(acc[0][m] + b0), v1 = rbf(acc[R - 1][m] + b1);
@@ -611,8 +633,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
                 dst[j + half] = f2bf(v1);
                 continue;
             }
-            const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + j;
-            const float c = bf2f(ra.cosT[cs]), sn = bf2f(ra.sinT[cs]);
+            const float c = e_cos[EPI == EPI_QKVROPE ? m : 0], sn = e_sin[EPI == EPI_QKVROPE ? m : 0];
             // TF:598-599 in bf16: bf16(bf16(x*cos) + bf16(rotate_half(x)*sin))
             const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
             const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
@@ -628,8 +649,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         for (int r = 0; r < R / 2; ++r) {
             const int no = grp * (R / 2) + r;
             if (no >= (N >> 1)) continue;
-            const float bg = bias ? bf2f(bias[rows[2 * r]]) : 0.f;
-            const float bu = bias ? bf2f(bias[rows[2 * r + 1]]) : 0.f;
+            const float bg = e_bias[2 * r];
+            const float bu = e_bias[2 * r + 1];
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const float g = rbf(acc[2 * r][m] + bg), u = rbf(acc[2 * r + 1][m] + bu);
@@ -641,11 +662,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         for (int r = 0; r < R; ++r) {
             const int n = rows[r];
             if (n >= N) continue;
-            const float bv = bias ? bf2f(bias[n]) : 0.f;
+            const float bv = e_bias[r];
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 float v = acc[r][m] + bv;
-                if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
+                if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[EPI == EPI_RESIDUAL ? r : 0][EPI == EPI_RESIDUAL ? m : 0];
                 if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
                 out[(size_t)m * ldo + n] = f2bf(v);
             }
