@@ -815,8 +815,16 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
     if (t >= D) return;
     const float* po = part_o + (size_t)bh * nsplit * D + t;
     float acc = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < nsplit; ++s) acc = fmaf(po[(size_t)s * D], sw[s], acc);
+    for (int s0 = 0; s0 < nsplit; s0 += 32) {  // 32 independent loads per round (a clamped index, weight 0 past the end)
+        float pv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int s = s0 + u;
+            pv[u] = po[(size_t)(s < nsplit ? s : nsplit - 1) * D];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = fmaf(pv[u], sw[(s0 + u) & 63], acc);
+    }
     out[(size_t)bh * D + t] = f2bf(acc * s_inv);
 }
 

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         // HBM latency of the weights runs under the norm instead of after it.
         constexpr int XC = 2;                        // x chunks per thread kept in registers (K <= 4096)
         const bool small = (nch <= XC * 256) && (M <= 4);
-        u32x4 xr[XC][M <= 4 ? M : 1];
+        u32x4 xr[XC][M <= 4 ? M : 1], wnr[XC];  // x chunks and the norm-weight chunks that go with them: one latency, not two
         float ss[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) ss[m] = 0.f;
@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int m = 0; m < (M <= 4 ? M : 1); ++m)
                     xr[i][m] = c < nch ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+                wnr[i] = c < nch ? *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
             }
         }
         if (c_begin < c_end) load_w(c_begin);
@@ -552,9 +553,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
             for (int i = 0; i < XC; ++i) {
                 const int c = threadIdx.x + i * 256;
                 if (c < nch) {
-                    const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
 #pragma unroll
-                    for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[i][m], wn);
+                    for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[i][m], wnr[i]);
                 }
             }
         } else {
