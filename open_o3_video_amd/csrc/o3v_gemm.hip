@@ -734,6 +734,32 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     int s_end = s_begin + per;
     s_end = s_end < nks ? s_end : nks;
 
+    // ---- epilogue operands of this lane (C[n = rb0 + 4*fg + r][m = fr]): requested now, a kernel's length ahead of their use
+    float e_bias[RB][4], e_res[4], e_cos[4], e_sin[4];
+    {
+        const int m = fr < M ? fr : 0;
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = rb0[b] + fg * 4 + r;
+                n = n < N ? n : N - 1;
+                e_bias[b][r] = bias ? bf2f(bias[n]) : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n = rb0[0] + fg * 4 + r;
+            n = n < N ? n : N - 1;
+            e_res[r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
+            if (EPI == EPI_QKVROPE) {
+                const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + (rb0[0] < N ? rb0[0] : 0) % ra.D + fg * 4 + r;
+                e_cos[r] = bf2f(ra.cosT[cs]);
+                e_sin[r] = bf2f(ra.sinT[cs]);
+            } else {
+                e_cos[r] = e_sin[r] = 0.f;
+            }
+        }
+    }
     // ---- weight stream, double buffered: two trips of U k-steps (UT KiB each) are in flight per wave, and the first one
     // is issued BEFORE the RMSNorm prologue so the HBM latency of the first weights hides the norm
     f32x4 acc[RB];
@@ -856,8 +882,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         for (int r = 0; r < 4; ++r) {
             const int no = no0 + r;
             if (no >= (N >> 1)) continue;
-            const float bg = bias ? bf2f(bias[rb0[0] + fg * 4 + r]) : 0.f;
-            const float bu = bias ? bf2f(bias[rb0[RB - 1] + fg * 4 + r]) : 0.f;
+            const float bg = e_bias[0][r], bu = e_bias[RB - 1][r];
             const float g = rbf(acc[0][r] + bg), u = rbf(acc[RB - 1][r] + bu);
             out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
         }
@@ -867,7 +892,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + r;
-            const float b0 = bias ? bf2f(bias[head * ra.D + j]) : 0.f, b1 = bias ? bf2f(bias[head * ra.D + j + half]) : 0.f;
+            const float b0 = e_bias[0][r], b1 = e_bias[RB - 1][r];
             const float v0 = rbf(acc[0][r] + b0), v1 = rbf(acc[RB - 1][r] + b1);
             if (head >= ra.Hq + ra.Hkv) {
                 bf16_t* dst = ra.vc + (((size_t)m * ra.Hkv + (head - ra.Hq - ra.Hkv)) * ra.Tmax + ra.slot) * ra.D;
@@ -875,8 +900,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
                 dst[j + half] = f2bf(v1);
                 continue;
             }
-            const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + j;
-            const float c = bf2f(ra.cosT[cs]), sn = bf2f(ra.sinT[cs]);
+            const float c = e_cos[r], sn = e_sin[r];
             const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
             const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
             bf16_t* dst = head < ra.Hq ? ra.qout + ((size_t)m * ra.Hq + head) * ra.D
@@ -889,8 +913,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         for (int r = 0; r < 4; ++r) {
             const int n = rb0[0] + fg * 4 + r;
             if (n >= N) continue;
-            float v = acc[0][r] + (bias ? bf2f(bias[n]) : 0.f);
-            if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
+            float v = acc[0][r] + e_bias[0][r];
+            if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[r];
             if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
             out[(size_t)m * ldo + n] = f2bf(v);
         }
