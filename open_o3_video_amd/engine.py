@@ -304,13 +304,15 @@ class O3VEngine:
         group = G if (G > 1 and tc.head_dim == 128 and own_splits <= 32 and self.group_attention) else 0
         mode = self.group_attention_mode
         if group:
-            # the one-pass kernel holds a group's query rows in 64 MFMA columns: larger groups run as sub-groups of the
-            # largest divisor of G that fits (every row carries its own copy of the prompt K/V, so any row can lead)
-            sub = max(d for d in range(1, G + 1) if G % d == 0 and d * n_rep <= 64)
+            # the one-pass kernel holds a sub-group's query rows as MFMA columns (<= 64); sub-groups of 4 rows measured best
+            # (every row carries its own copy of the prompt K/V, so any row can lead a sub-group)
+            sub = max(d for d in range(1, G + 1) if G % d == 0 and d <= 4 and d * n_rep <= 64)
             if mode == "auto":
-                # measured, 7B dims (tools/measure_configs.py rollout / rollout_eval): G=8, S=4.5k: the per-row kernel reading
-                # the leader's prefix through the shared L2 wins (4.56 vs 4.80 ms/step; neither: 4.73); S=10k: the one-pass
-                # group kernel does (4.96 vs 5.08; neither: 5.42); G=16: shared-read is L2-bound (39 us/layer)
+                # measured, 7B dims, ms per decode step (tools/measure_configs.py rollout / rollout_eval):
+                #   G=8  S=4.5k: per-row kernel reading the leader's prefix through the shared L2 3.86 | one-pass, sub-groups
+                #                of 2 / 4 / 8 rows 4.00 / 4.06 / 4.13
+                #   G=8  S=10k : shared-read 4.37 | one-pass 4.44 / 4.15 / 4.25
+                #   G=16 S=4.5k: shared-read 4.88 (L2-bound) | one-pass 4.81 / 4.81 / 5.13
                 mode = "kernel" if (S >= 8192 or B >= 12) and sub > 1 else "shared_read"
             if mode == "kernel" and sub > 1:
                 group = sub
