@@ -266,8 +266,10 @@ class O3VEngine:
                 vc0[:, :, :, :past].copy_(ent["v"][:, :, :, :past])
             self.prefill(x, pos[:, :, past:], pad, B0, S - past, kc0, vc0, past=past)
             # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
-            kc[:, :, :, :S].copy_(kc0.repeat_interleave(G, dim=1) if G > 1 else kc0)
-            vc[:, :, :, :S].copy_(vc0.repeat_interleave(G, dim=1) if G > 1 else vc0)
+            # (a broadcast copy into the [layers, B0, G, ...] view of the caches: no G-times temporary)
+            shp = (kc.shape[0], B0, G) + tuple(kc.shape[2:])
+            kc.view(shp)[:, :, :, :, :S].copy_(kc0[:, :, None])
+            vc.view(shp)[:, :, :, :, :S].copy_(vc0[:, :, None])
             if use_prefix:
                 self._prefix_store(prefix_key, ids[0], kc0, vc0)
             del kc0, vc0

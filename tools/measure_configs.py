@@ -26,7 +26,7 @@ def run(tag, frames_n, H, W, S_target, T, **kw):
     ids = build_prompt(cfg, frames_n, tpf, S_target)
     g = torch.Generator(device=dev).manual_seed(1)
     frames = torch.randint(0, 256, (frames_n, 3, H, W), generator=g, dtype=torch.uint8, device=dev)
-    eng.generate([ids], None, frames=frames, max_new_tokens=8, **kw)  # warm-up
+    eng.generate([ids], None, frames=frames, max_new_tokens=T, **kw)  # warm-up with the same shapes (allocator, code paths)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = eng.generate([ids], None, frames=frames, max_new_tokens=T, return_margins=False, sync_timings=True, **kw)
