@@ -454,17 +454,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // is consumed by the 4 k-steps of one lane quad), V staged by the wave into its private LDS slice and read back
 // transposed (ds_read_b64_tr_b16).  ~32 MFMA + ~100 VALU per 32 keys instead of ~1600 VALU in the scalar kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
-                                                               const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
-                                                               float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
-                                                               int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
-                                                               float scale_log2e, int kbeg, int nsplit_tot, int split_off,
-                                                               int G, int P) {
+__device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                      const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                      float* __restrict__ part_ml, const int* __restrict__ k_lo_arr, int ctx,
+                                                      int Hq, int Hkv, int n_rep, long k_hs, long k_bs, float scale_log2e,
+                                                      int kbeg, int nsplit_tot, int split_off, int G, int P, const int split,
+                                                      const int nsplit, const int hk, const int b) {
     // keys kbeg..ctx-1 of every row; partials go to slots split_off.. of the row's nsplit_tot (the slots before
     // split_off belong to attn_decode_group_kernel when the rows of a group share their first kbeg keys)
     constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE;  // 9216 B per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];               // 4 x V slice, reused for the merge
-    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int k_lo = k_lo_arr ? k_lo_arr[b] : 0;
@@ -608,6 +607,16 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
     }
 }
 
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                               const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                               float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
+                                                               int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
+                                                               float scale_log2e, int kbeg, int nsplit_tot, int split_off,
+                                                               int G, int P) {
+    attn_decode_mfma_body(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, kbeg, nsplit_tot,
+                          split_off, G, P, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Group decode attention over a SHARED prompt prefix (head_dim 128).  The G completions of one prompt
 // (num_return_sequences, R:grpo_trainer.py:306-313; n samples, R:eval/tts.py:47-123) attend to the same first
@@ -617,15 +626,16 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
 // K/V of the prefix are read from the cache row of the group's first sequence.
 // ------------------------------------------------------------------------------------------------
 template <int NQB>
-__global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
-                                                                const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
-                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
-                                                                int P, int G, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
-                                                                float scale_log2e, int nsplit_tot) {
+__device__ __forceinline__ void attn_decode_group_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                       const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                       float* __restrict__ part_ml, const int* __restrict__ k_lo_arr, int P, int G,
+                                                       int Hq, int Hkv, int n_rep, long k_hs, long k_bs, float scale_log2e,
+                                                       int nsplit_tot, const int split, const int nsplit, const int hk,
+                                                       const int grp) {
     constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE, QSTRIDE = 272, NQ = NQB * 16;
     constexpr int Q_BYTES = NQ * QSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // Q rows | 4 x V slice ; reused: so[NQ][128] | sm | sl
-    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b0 = blockIdx.z * G;
+    const int b0 = grp * G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int k_lo = k_lo_arr ? k_lo_arr[b0] : 0;
@@ -792,6 +802,27 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __
     }
 }
 
+// One launch for a decode step's group attention: blocks [0, n_prefix) run the shared-prefix role for (split, kv head,
+// sub-group), the rest the own-keys role for (split, kv head, row) -- both only write partials, the combine follows.
+template <int NQB>
+__global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
+                                                                const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
+                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
+                                                                int P, int G, int ctx, int Hq, int Hkv, int n_rep, long k_hs,
+                                                                long k_bs, float scale_log2e, int nsplit_prefix, int nsplit_own,
+                                                                int n_prefix) {
+    const int nsplit_tot = nsplit_prefix + nsplit_own;
+    int L = blockIdx.x;
+    if (L < n_prefix) {
+        attn_decode_group_body<NQB>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, P, G, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, nsplit_tot,
+                                    L % nsplit_prefix, nsplit_prefix, (L / nsplit_prefix) % Hkv, L / (nsplit_prefix * Hkv));
+    } else {
+        L -= n_prefix;
+        attn_decode_mfma_body(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, P, nsplit_tot,
+                              nsplit_prefix, 1, 0, L % nsplit_own, nsplit_own, (L / nsplit_own) % Hkv, L / (nsplit_own * Hkv));
+    }
+}
+
 // Merge the context splits: block per (b, head); split weights are computed once into LDS, then every thread sums its
 // output dimension over the splits with independent loads.
 template <int D>
@@ -928,14 +959,15 @@ extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* 
     const float sl2 = scale * 1.4426950408889634f;
     const long k_hs = (long)Tmax * D, k_bs = (long)Hkv * Tmax * D;
     const int nqb = (G * n_rep + 15) / 16;
-    dim3 grid(nsplit_prefix, Hkv, B / G), block(256);
+    const int n_prefix = nsplit_prefix * Hkv * (B / G), n_own = nsplit_own * Hkv * B;
+    dim3 grid(n_prefix + n_own), block(256);
 #define O3V_AG(NQB)                                                                                                         \
     O3V_KLAUNCH((attn_decode_group_kernel<NQB>), grid, block,                                                                \
                 (size_t)((NQB * 16 * 272 + 4 * 32 * 288) > (NQB * 16 * 128 * 4 + 5 * NQB * 16 * 4)                         \
                              ? (NQB * 16 * 272 + 4 * 32 * 288)                                                              \
                              : (NQB * 16 * 128 * 4 + 5 * NQB * 16 * 4)),                                                    \
-                stream, (const bf16_t*)Q, (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, prefix_len, G, Hq,   \
-                Hkv, n_rep, k_hs, k_bs, sl2, nsplit_tot)
+                stream, (const bf16_t*)Q, (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, prefix_len, G, ctx, Hq, \
+                Hkv, n_rep, k_hs, k_bs, sl2, nsplit_prefix, nsplit_own, n_prefix)
     if (nqb == 1)
         O3V_AG(1);
     else if (nqb == 2)
@@ -945,9 +977,6 @@ extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* 
     else
         O3V_AG(4);
 #undef O3V_AG
-    O3V_KLAUNCH(attn_decode_mfma_kernel, dim3(nsplit_own, Hkv, B), block, 4 * 32 * 288, stream, (const bf16_t*)Q,
-                (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2, prefix_len,
-                nsplit_tot, nsplit_prefix, 1, 0);
     O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml, (bf16_t*)out,
                 nsplit_tot);
     O3V_CHECK_LAUNCH();
