@@ -313,12 +313,11 @@ class O3VEngine:
             # (every row carries its own copy of the prompt K/V, so any row can lead a sub-group)
             sub = max(d for d in range(1, G + 1) if G % d == 0 and d <= 4 and d * n_rep <= 64)
             if mode == "auto":
-                # measured, 7B dims, ms per decode step (tools/measure_configs.py rollout / rollout_eval):
-                #   G=8  S=4.5k: per-row kernel reading the leader's prefix through the shared L2 3.86 | one-pass, sub-groups
-                #                of 2 / 4 / 8 rows 4.00 / 4.06 / 4.13
-                #   G=8  S=10k : shared-read 4.37 | one-pass 4.44 / 4.15 / 4.25
-                #   G=16 S=4.5k: shared-read 4.88 (L2-bound) | one-pass 4.81 / 4.81 / 5.13
-                mode = "kernel" if (S >= 8192 or B >= 12) and sub > 1 else "shared_read"
+                # measured, 7B dims, ms per decode step (tools/measure_configs.py rollout / rollout_eval), per-row kernel reading
+                # the leader's prefix through the shared L2 | one-pass kernel in sub-groups of 4 (prefix + own keys, one launch):
+                #   S=4.5k: G=4 3.45 | 3.53   G=8 3.71 | 3.79   G=12 4.06 | 4.09   G=16 4.42 | 4.36
+                #   S=10k : G=8 4.37 | 3.97
+                mode = "kernel" if (S >= 8192 or B >= 16) and sub > 1 else "shared_read"
             if mode == "kernel" and sub > 1:
                 group = sub
                 # prefix splits: ~320 blocks in all (measured: G=16, S=4.5k 36 -> 18 splits 4.80 -> 4.63 ms/step; G=8, S=10k is
