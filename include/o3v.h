@@ -94,6 +94,9 @@ int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const v
 int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int ldx,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 
+/* A/B switch of the M == 1 GEMV's CU-balanced workgroup sizes (default on; 0 = always four waves per workgroup). */
+int o3v_gemv_set_balanced(int on);
+
 /* RMSNorm (TF:65-79) fused into the projection that consumes it: out = epi(rmsnorm(X; norm_w, eps) . W^T + bias), M <= 8.
  * Removes one launch per q/k/v, gate/up and lm_head projection of a decode step. */
 int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void* W, const void* bias, const void* res,
@@ -132,6 +135,24 @@ int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, fl
 int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                           const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
                           int nsplit_prefix, float scale, o3v_stream_t stream);
+
+/* One launch for the attention half of a batch-1 decode layer (TF:692-757 first half; replaces o3v_gemv_norm_qkv_rope +
+ * o3v_attn_decode + o3v_linear_decode(o_proj, RESIDUAL), bit-identical to them): the three stages are roles of the
+ * workgroups of one grid, handing q / the new K,V row / the split partials / the attention output to one another through
+ * write-through stores, tickets and per-workgroup mailbox lines in `sync` (o3v_decode_sync_bytes() bytes, 128-byte aligned,
+ * zeroed ONCE by the caller; `epoch` = 1, 2, 3, ... counts the launches made on that buffer, with the same nsplit, Hq, Hkv).
+ * The word at byte O3V_SYNC_TMO_BYTE of `sync` is a sticky time-out flag (non-zero: a bounded wait gave up, results invalid).
+ * x bf16 [H]: residual stream, normalised by ln_w for q/k/v and updated in place by o_proj.  Returns O3V_ERR_SHAPE when
+ * the shapes (head_dim 128, Hkv <= 8, H and Hq*D <= 4096 in a built combination) or the chip's residency do not allow
+ * the fused form: call the three stand-alone entries instead. */
+#define O3V_SYNC_TMO_BYTE 2048
+size_t o3v_decode_sync_bytes(void);
+int o3v_decode_attn_block_capacity(int h, int qd); /* workgroups of the fused kernel resident at once; 0: shape not built */
+int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
+                          const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
+                          float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax,
+                          int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
+                          o3v_stream_t stream);
 
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
@@ -236,6 +257,9 @@ typedef struct {
     size_t prefetch_bytes;       /* bytes of the next projections' weights to pull on-die per layer */
     int group;                   /* > 1: rows g*group..g*group+group-1 share their first S keys -> o3v_attn_decode_group
                                     (nsplit is then the prefix split count; part_o/part_ml hold 64 splits) */
+    uint32_t *sync;              /* optional: o3v_decode_sync_bytes() bytes, 128-byte aligned, zeroed by the caller before the
+                                    first step of a generate call.  Non-NULL selects the one-launch attention block
+                                    (o3v_decode_attn_block) where its shapes allow (B == 1) */
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

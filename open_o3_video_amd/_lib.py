@@ -43,7 +43,7 @@ class DecodeState(C.Structure):
                 ("x", vp), ("kcache", vp), ("vcache", vp), ("cosT", vp), ("sinT", vp), ("logits", vp), ("seen", vp),
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
-                ("ws_bytes", sz), ("side_stream", vp), ("prefetch_bytes", sz), ("group", i32)]
+                ("ws_bytes", sz), ("side_stream", vp), ("prefetch_bytes", sz), ("group", i32), ("sync", vp)]
 
 
 # name -> argtypes (return type int unless listed in _RET)
@@ -64,10 +64,15 @@ SIGNATURES = {
     "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
     "o3v_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "o3v_gemm_set_tile": [i32],
+    "o3v_gemv_set_balanced": [i32],
     "o3v_gemm_bf16_splitk": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp],
     "o3v_resize_bicubic_aa": [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp],
     "o3v_crop_resize_bilinear": [vp, vp, vp, i32, i32, i32, i32, vp],
     "o3v_attn_decode_group": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "o3v_decode_sync_bytes": [],
+    "o3v_decode_attn_block_capacity": [i32, i32],
+    "o3v_decode_attn_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                              i32, f32, vp, C.c_uint32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -83,8 +88,9 @@ SIGNATURES = {
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }
-_RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz}
+_RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
 
+SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
 SAMPLE_SCRATCH_FLOATS = 24576   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h
 
 _lib = None
@@ -109,7 +115,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
             fn.argtypes = args
             fn.restype = _RET.get(name, i32)
-        if lib.o3v_abi_version() != 1:
+        if lib.o3v_abi_version() != 2:
             raise O3VError("libo3v_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libo3v_hip.so")
-SOURCES = ["o3v_elem.hip", "o3v_gemm.hip", "o3v_attn.hip", "o3v_sample.hip", "o3v_engine.hip"]
+SOURCES = ["o3v_elem.hip", "o3v_gemm.hip", "o3v_attn.hip", "o3v_fused.hip", "o3v_sample.hip", "o3v_engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -28,16 +28,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, extra_flags=(), lib: str = LIB, objdir: str = "build") -> str:
+    """extra_flags / lib / objdir: diagnostic variants (e.g. -DO3V_STAMPS for tools/probe_fused.py) built beside the product library."""
+    if not force and lib == LIB and not needs_build():
         return LIB
     hipcc = find_hipcc()
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     procs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -46,11 +47,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

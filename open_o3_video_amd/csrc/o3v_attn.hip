@@ -15,10 +15,10 @@
 //   permuted consistently), A = V^T fetched with ds_read_b64_tr_b16 from the row-major V tile.
 // fp32 scores/softmax/accumulators; P is rounded to bf16 before P.V as the reference's bf16 attention does.
 #include "o3v_common.h"
+#include "o3v_attn_decode_body.h"
 
 namespace {
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 struct TileDesc {  // 8 ints, built on the host (open_o3_video_amd/indexing.py)
@@ -303,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
 // query heads of the kv head share every K/V byte (GQA).  Each (wave, slot) is an independent online
 // softmax stream; streams are merged at the end, splits by o3v_attn_decode_combine.
 // ------------------------------------------------------------------------------------------------
-constexpr int NREP_MAX = 8;
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
@@ -447,174 +446,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Decode attention on the matrix cores (head_dim 128).  Same swapped-QK^T scheme as attn_tiles_kernel with the
-// n_rep query heads of a kv head as the 16 "query rows" (GQA: K/V bytes are read once for the whole group):
-// each wave walks its own key range in 32-key tiles -- K fragments straight from global memory to VGPRs (a key row
-// is consumed by the 4 k-steps of one lane quad), V staged by the wave into its private LDS slice and read back
-// transposed (ds_read_b64_tr_b16).  ~32 MFMA + ~100 VALU per 32 keys instead of ~1600 VALU in the scalar kernel.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
-                                                      const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
-                                                      float* __restrict__ part_ml, const int* __restrict__ k_lo_arr, int ctx,
-                                                      int Hq, int Hkv, int n_rep, long k_hs, long k_bs, float scale_log2e,
-                                                      int kbeg, int nsplit_tot, int split_off, int G, int P, const int split,
-                                                      const int nsplit, const int hk, const int b) {
-    // keys kbeg..ctx-1 of every row; partials go to slots split_off.. of the row's nsplit_tot (the slots before
-    // split_off belong to attn_decode_group_kernel when the rows of a group share their first kbeg keys)
-    constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE;  // 9216 B per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];               // 4 x V slice, reused for the merge
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int k_lo = k_lo_arr ? k_lo_arr[b] : 0;
-    char* Vl = smem + wave * V_BYTES;
-
-    int chunk = (ctx - kbeg + nsplit - 1) / nsplit;
-    chunk = (chunk + 4 * KT - 1) / (4 * KT) * (4 * KT);  // whole 32-key tiles per wave
-    const int per_wave = chunk >> 2;
-    const int kw0 = kbeg + split * chunk + wave * per_wave;
-    int kw1 = kw0 + per_wave;
-    kw1 = kw1 < ctx ? kw1 : ctx;
-
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        if (fr < n_rep)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ((size_t)b * Hq + hk * n_rep + fr) * D + ks * 32 + fg * 8);
-        else
-            qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    const bf16_t* Kb = Kc + (size_t)b * k_bs + (size_t)hk * k_hs;
-    const bf16_t* Vb = Vc + (size_t)b * k_bs + (size_t)hk * k_hs;
-    // G > 1: keys below P are read from the cache row of the group's first sequence (identical bytes for the G rows of a
-    // group, whose blocks share an XCD and hence an L2: one HBM read serves the group)
-    const size_t lead = G > 1 ? (size_t)(b - (b / G) * G) * k_bs : 0;
-    const bf16_t* Kl = Kb - lead;
-    const bf16_t* Vl0 = Vb - lead;
-
-    float m_run = -1e30f, l_run = 0.f;
-    f32x4 o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int tq = fr >> 2, tp = fr & 3;
-
-    for (int key0 = kw0; key0 < kw1; key0 += KT) {
-        // ---- K fragments (A operand): lane (key = fr, quad fg) loads 16 B of row key0 + kb*16 + fr
-        bf16x8 kf[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            int kr = key0 + kb * 16 + fr;
-            kr = kr < ctx ? kr : ctx - 1;
-            const bf16_t* Kr = (kr < P ? Kl : Kb) + (size_t)kr * D;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Kr + ks * 32 + fg * 8);
-        }
-        // ---- V tile -> this wave's LDS slice (32 rows x 16 chunks of 16 B, 8 per lane)
-        u32x4 vreg[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = i * 64 + lane, row = c >> 4, ch = c & 15;
-            int kr = key0 + row;
-            kr = kr < ctx ? kr : ctx - 1;
-            vreg[i] = *reinterpret_cast<const u32x4*>((kr < P ? Vl0 : Vb) + (size_t)kr * D + ch * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = i * 64 + lane, row = c >> 4, ch = c & 15;
-            *reinterpret_cast<u32x4*>(Vl + row * VSTRIDE + ch * 16) = vreg[i];
-        }
-        // ---- S^T = K . Q^T
-        f32x4 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
-        }
-        float mx = -1e30f;
-        bool ok[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = key0 + kb * 16 + fg * 4 + r;
-                ok[kb][r] = (j < kw1) && (j >= k_lo);
-                const float sv = ok[kb][r] ? s[kb][r] * scale_log2e : -1e30f;
-                s[kb][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pb;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = ok[kb][r] ? __builtin_amdgcn_exp2f(s[kb][r] - m_new) : 0.f;
-                const bf16_t pq = f2bf(p);
-                psum += bf2f(pq);
-                pb[kb * 4 + r] = (short)pq;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] *= alpha;
-        // ---- O^T += V^T . P^T   (LDS ops of one wave execute in order: the tr-reads see the stores above)
-        const char* r0 = Vl + (fg * 4 + tq) * VSTRIDE + tp * 8;
-        const char* r1 = r0 + 16 * VSTRIDE;
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r0 + db * 32));
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(r1 + db * 32));
-            const bf16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, o[db], 0, 0, 0);
-        }
-    }
-    // ---- merge the 4 waves: so[w][q][d], sm/sl[w][q] in LDS (the V slices are dead)
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    __syncthreads();
-    float* so = reinterpret_cast<float*>(smem);           // [4][16][128] = 32 KiB
-    float* sm = so + 4 * 16 * D;                           // [4][16]
-    float* sl = sm + 64;                                   // [4][16]
-#pragma unroll
-    for (int db = 0; db < 8; ++db)
-        *reinterpret_cast<f32x4*>(so + ((size_t)(wave * 16 + fr) * D + db * 16 + fg * 4)) = o[db];
-    if (fg == 0) {
-        sm[wave * 16 + fr] = m_run;
-        sl[wave * 16 + fr] = l_tot;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_rep * D; i += 256) {
-        const int q = i / D, d = i % D;
-        const float mn = fmaxf(fmaxf(sm[q], sm[16 + q]), fmaxf(sm[32 + q], sm[48 + q]));
-        float acc = 0.f, lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float sc = __builtin_amdgcn_exp2f(sm[w * 16 + q] - mn);
-            acc += so[(size_t)(w * 16 + q) * D + d] * sc;
-            lt += sl[w * 16 + q] * sc;
-        }
-        const size_t idx = (((size_t)b * Hq + hk * n_rep + q) * nsplit_tot + split_off + split);
-        part_o[idx * D + d] = acc;
-        if (d == 0) {
-            part_ml[idx * 2] = mn;
-            part_ml[idx * 2 + 1] = lt;
-        }
-    }
-}
-
+// Decode attention on the matrix cores: attn_decode_mfma_body in o3v_attn_decode_body.h (shared with o3v_fused.hip)
 __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
                                                                const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
                                                                int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
                                                                float scale_log2e, int kbeg, int nsplit_tot, int split_off,
                                                                int G, int P) {
-    attn_decode_mfma_body(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, kbeg, nsplit_tot,
-                          split_off, G, P, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 x V slice, reused for the merge
+    attn_decode_mfma_body<false>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, kbeg,
+                                 nsplit_tot, split_off, G, P, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, smem, AttnHandoff{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,6 +652,7 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __
                                                                 int P, int G, int ctx, int Hq, int Hkv, int n_rep, long k_hs,
                                                                 long k_bs, float scale_log2e, int nsplit_prefix, int nsplit_own,
                                                                 int n_prefix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nsplit_tot = nsplit_prefix + nsplit_own;
     int L = blockIdx.x;
     if (L < n_prefix) {
@@ -818,8 +660,9 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __
                                     L % nsplit_prefix, nsplit_prefix, (L / nsplit_prefix) % Hkv, L / (nsplit_prefix * Hkv));
     } else {
         L -= n_prefix;
-        attn_decode_mfma_body(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, P, nsplit_tot,
-                              nsplit_prefix, 1, 0, L % nsplit_own, nsplit_own, (L / nsplit_own) % Hkv, L / (nsplit_own * Hkv));
+        attn_decode_mfma_body<false>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, P,
+                                     nsplit_tot, nsplit_prefix, 1, 0, L % nsplit_own, nsplit_own, (L / nsplit_own) % Hkv,
+                                     L / (nsplit_own * Hkv), smem, AttnHandoff{});
     }
 }
 
@@ -833,29 +676,10 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
     __shared__ float s_inv;
     const int bh = blockIdx.x;  // b*Hq + h
     const int t = threadIdx.x;
-    if (t < 64) {
-        const float mv = t < nsplit ? part_ml[((size_t)bh * nsplit + t) * 2] : -1e30f;
-        const float lv = t < nsplit ? part_ml[((size_t)bh * nsplit + t) * 2 + 1] : 0.f;
-        const float mn = wave_max(mv);
-        const float w = t < nsplit ? __builtin_amdgcn_exp2f(mv - mn) : 0.f;
-        const float lt = wave_sum(lv * w);
-        sw[t] = w;
-        if (t == 0) s_inv = lt > 0.f ? 1.0f / lt : 0.f;
-    }
+    if (t < 64) combine_weights<false>(part_ml, bh, nsplit, sw, &s_inv, t);
     __syncthreads();
     if (t >= D) return;
-    const float* po = part_o + (size_t)bh * nsplit * D + t;
-    float acc = 0.f;
-    for (int s0 = 0; s0 < nsplit; s0 += 32) {  // 32 independent loads per round (a clamped index, weight 0 past the end)
-        float pv[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int s = s0 + u;
-            pv[u] = po[(size_t)(s < nsplit ? s : nsplit - 1) * D];
-        }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) acc = fmaf(pv[u], sw[(s0 + u) & 63], acc);
-    }
+    const float acc = combine_dim<D, false>(part_o, bh, nsplit, sw, t);
     out[(size_t)bh * D + t] = f2bf(acc * s_inv);
 }
 

@@ -50,7 +50,7 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
-extern "C" int o3v_abi_version(void) { return 1; }
+extern "C" int o3v_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------------------ ViT
 extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
@@ -251,8 +251,43 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // at B=8, 75 -> 50 us at B=16 (profiles/r01_m8_linear.txt).  Whole step, 7B: B=4 3.56 -> 3.61 ms (worse: two more
     // launches per layer), B=8 4.04 -> 3.97, B=16 5.63 -> 5.25: taken from B=8 on.
     const bool norm_apart = B >= 8;
+    // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
+    bool fused = st->sync && B == 1 && st->group <= 1 && !(st->side_stream && st->prefetch_bytes) && st->nsplit > 0;
+    int step = step0;
+    // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
+    auto attention_half = [&](int l) -> int {
+        const o3v_llm_layer_w& lw = d->layer[l];
+        char* kc = (char*)st->kcache + l * layer_stride;
+        char* vc = (char*)st->vcache + l * layer_stride;
+        if (norm_apart) {
+            TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+            TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
+                                       st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+        } else {
+            TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
+                                       kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+        }
+        if (st->side_stream && st->prefetch_bytes) {
+            hipEvent_t ev = ev_ring[ev_i++ & 7];
+            if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
+                return O3V_ERR_LAUNCH;
+            const size_t pb = st->prefetch_bytes;
+            TRY(o3v_prefetch(lw.o_w, pb < o_bytes ? pb : o_bytes, 48, st->part_ml, st->side_stream));
+            if (pb > o_bytes)
+                TRY(o3v_prefetch(lw.gu_w, (pb - o_bytes) < gu_bytes ? (pb - o_bytes) : gu_bytes, 48, st->part_ml,
+                                 st->side_stream));
+        }
+        if (st->group > 1)  // the rows of a group share the prompt K/V: read it once per group
+            TRY(o3v_attn_decode_group(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D, st->S,
+                                      st->S + step + 1, st->Tmax, st->nsplit, scale, s));
+        else
+            TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1, st->Tmax,
+                                st->nsplit, scale, s));
+        TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        return O3V_OK;
+    };
     for (int i = 0; i < n_steps; ++i) {
-        const int step = step0 + i;
+        step = step0 + i;
         if (st->do_sample)
             TRY(o3v_sample_top_p(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
                                  st->n_eos, st->pad_id, B, V, V, st->rep_penalty, st->temperature, st->top_p, st->seed,
@@ -269,32 +304,17 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
-            if (norm_apart) {
-                TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
-                TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc,
-                                           vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
-            } else {
-                TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT,
-                                           w.q, kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+            if (fused) {
+                const int rc = o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q,
+                                                     w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step,
+                                                     st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync,
+                                                     (uint32_t)(step * d->layers + l + 1), s);
+                if (rc == O3V_ERR_SHAPE && l == 0)
+                    fused = false;  // shapes or residency do not allow the one-launch form: the stand-alone kernels instead
+                else if (rc != O3V_OK)
+                    return rc;
             }
-            if (st->side_stream && st->prefetch_bytes) {
-                hipEvent_t ev = ev_ring[ev_i++ & 7];
-                if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
-                    return O3V_ERR_LAUNCH;
-                const size_t pb = st->prefetch_bytes;
-                TRY(o3v_prefetch(lw.o_w, pb < o_bytes ? pb : o_bytes, 48, st->part_ml, st->side_stream));
-                if (pb > o_bytes)
-                    TRY(o3v_prefetch(lw.gu_w, (pb - o_bytes) < gu_bytes ? (pb - o_bytes) : gu_bytes, 48, st->part_ml,
-                                     st->side_stream));
-            }
-            if (st->group > 1)  // the rows of a group share the prompt K/V: read it once per group
-                TRY(o3v_attn_decode_group(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D, st->S,
-                                          st->S + step + 1, st->Tmax, st->nsplit, scale, s));
-            else
-                TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1,
-                                    st->Tmax, st->nsplit, scale, s));
-            TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H,
-                                  O3V_EPI_RESIDUAL, s));
+            if (!fused) TRY(attention_half(l));
             if (norm_apart) {
                 TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,

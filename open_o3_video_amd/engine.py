@@ -66,6 +66,7 @@ class O3VEngine:
         self.prefetch_bytes = int(float(os.environ.get("O3V_PREFETCH_MB", "0")) * 1e6)
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.prefetch_bytes > 0 else None
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
+        self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
 
     # ------------------------------------------------------------------------------------------ vision
@@ -333,6 +334,10 @@ class O3VEngine:
         xdec = torch.empty((B, H), dtype=torch.bfloat16, device=self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        # tickets / mailboxes of the one-launch attention block (batch 1): zeroed once per call, epochs count the launches
+        sync = None
+        if self.fused_decode and B == 1:
+            sync = torch.zeros(_lib.load().o3v_decode_sync_bytes(), dtype=torch.uint8, device=self.dev)
         st = _lib.DecodeState(B=B, S=S, Tmax=Tmax, Tnew=T, nsplit=nsplit, pad_id=pad_id, n_eos=len(eos_token_ids),
                               do_sample=int(do_sample), rep_penalty=float(repetition_penalty), temperature=float(temperature),
                               top_p=float(top_p), seed=int(seed) & (2 ** 64 - 1), x=xdec.data_ptr(), kcache=kc.data_ptr(),
@@ -343,7 +348,7 @@ class O3VEngine:
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
                               sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
                               ws_bytes=nbytes, side_stream=0 if self.side_stream is None else self.side_stream.cuda_stream,
-                              prefetch_bytes=self.prefetch_bytes, group=group)
+                              prefetch_bytes=self.prefetch_bytes, group=group, sync=0 if sync is None else sync.data_ptr())
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
         use_eos = len(eos_token_ids) > 0
@@ -355,6 +360,10 @@ class O3VEngine:
             if use_eos and done < T and bool(finished.all().item()):
                 break
         mark(3)
+        if sync is not None:
+            code = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+            if code:
+                raise _lib.O3VError(f"decode: an in-launch wait gave up (code {code:#x}); results are invalid")
         gen = out_ids[:, :done].to(torch.int64)
         if use_eos and done > 0:
             # HF stops at the step where every row has finished: trim trailing all-pad columns generated past it

@@ -695,3 +695,73 @@ def test_resize_bicubic_antialias(dev, T, H, W, h, w):
     assert out_u.min().item() >= 0 and out_u.max().item() <= 255 and torch.equal(out_u, out_u.round())
     if (h, w) == (H, W):
         assert torch.equal(out_u, fr.float())
+
+
+@pytest.mark.parametrize("Hq,Hkv,H,ctx,Tmax,nsplit,pad", [
+    (28, 4, 3584, 4491, 5002, 40, 0),      # 7B, first decode step of the bench prompt
+    (28, 4, 3584, 5002, 5002, 40, 37),     # last slot of the cache, left-padded prompt
+    (16, 2, 2048, 1500, 1732, 14, 0),      # 3B dims (n_rep 8)
+    (32, 8, 4096, 300, 512, 4, 0),         # 8 kv heads (Qwen3-VL-8B text dims), short context: empty waves / splits
+    (28, 4, 3584, 97, 20480, 64, 3),       # few keys against 64 splits: most workgroups hold no key at all
+    (14, 2, 896, 1, 64, 1, 0),             # one key (the token itself)
+])
+def test_decode_attn_block_fused_equals_three_launches(dev, Hq, Hkv, H, ctx, Tmax, nsplit, pad):
+    """o3v_decode_attn_block (one launch, roles + in-launch hand-offs) == o3v_gemv_norm_qkv_rope + o3v_attn_decode +
+    o3v_linear_decode(o_proj, RESIDUAL) BIT FOR BIT: residual stream, q, attention output, the appended K/V row.
+    Run three times on the same buffers (L1/L2-warm consumers, epochs 1..3 on one sync buffer) with new inputs each time."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    D, Tnew, step = 128, 7, 3
+    slot = ctx - 1
+    g = torch.Generator().manual_seed(Hq * 1000 + ctx)
+    N, QD = (Hq + 2 * Hkv) * D, Hq * D
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    wqkv = (torch.randn(N, H, generator=g) / math.sqrt(H)).to(BF).to(dev)
+    bqkv = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    wo = (torch.randn(H, QD, generator=g) / math.sqrt(QD)).to(BF).to(dev)
+    ang = torch.rand(1, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    kc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    vc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    kc0[:, :, slot] = float("nan")   # the slot of the new token holds garbage until the q/k/v role fills it
+    vc0[:, :, slot] = float("nan")
+    k_lo = torch.tensor([pad], dtype=torch.int32, device=dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)   # zeroed once; epochs 1, 2, 3 below
+    part_o = torch.empty(Hq * 64 * D, dtype=torch.float32, device=dev)
+    part_ml = torch.empty(Hq * 64 * 2, dtype=torch.float32, device=dev)
+    q2, att2 = torch.zeros(1, Hq, D, dtype=BF, device=dev), torch.zeros(1, Hq, D, dtype=BF, device=dev)
+    k2, v2 = kc0.clone(), vc0.clone()
+    for rep in range(3):
+        x0 = (torch.randn(1, H, generator=g) * 2).to(BF).to(dev)
+        # ---- three stand-alone launches
+        x1 = x0.clone()
+        q1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        k1, v1 = kc0.clone(), vc0.clone()
+        att1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        po1, pm1 = torch.empty_like(part_o), torch.empty_like(part_ml)
+        _lib.call("o3v_gemv_norm_qkv_rope", P(x1), P(nw), 1e-6, P(wqkv), None, P(bqkv), 1, H, H, P(cos), P(sin), P(q1), P(k1), P(v1),
+                  slot, Hq, Hkv, D, Tmax, Tnew, step, st)
+        _lib.call("o3v_attn_decode", P(q1), P(k1), P(v1), P(att1), P(po1), P(pm1), P(k_lo), 1, Hq, Hkv, D, ctx, Tmax, nsplit,
+                  scale, st)
+        _lib.call("o3v_linear_decode", P(att1), None, 0.0, P(wo), None, None, P(x1), P(x1), 1, H, QD, QD, H, H, _lib.EPI_RESIDUAL, st)
+        # ---- one launch (same buffers every repetition: consumers find the previous repetition's lines in their caches)
+        x2 = x0.clone()
+        k2[:, :, slot] = float("nan")
+        v2[:, :, slot] = float("nan")
+        rc = lib.o3v_decode_attn_block(P(x2), P(nw), 1e-6, P(wqkv), P(bqkv), P(wo), P(cos), P(sin), P(q2), P(att2), P(k2), P(v2),
+                                       P(part_o), P(part_ml), P(k_lo), H, Hq, Hkv, D, slot, Tmax, Tnew, step, nsplit, scale,
+                                       P(sync), rep + 1, st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        tmo = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+        assert tmo == 0, f"an in-launch wait timed out (code {tmo:#x})"
+        assert not torch.isnan(x1.float()).any()
+        assert torch.equal(q2.view(torch.int16), q1.view(torch.int16))
+        assert torch.equal(k2.view(torch.int16), k1.view(torch.int16)) and torch.equal(v2.view(torch.int16), v1.view(torch.int16))
+        assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
