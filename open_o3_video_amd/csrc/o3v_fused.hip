@@ -86,6 +86,9 @@ __device__ __forceinline__ void oproj_role(const FusedArgs& a, const int bid) {
                 wv[i][r] = __builtin_nontemporal_load(wp[r] + (in ? c : 0));
                 if (!in) wv[i][r] = (u32x4){0, 0, 0, 0};
             }
+#ifdef O3V_STAMPS
+            for (int p = 0; p < ((a.knob >> 5) & 7); ++p) __builtin_amdgcn_s_sleep(16);  // ablation: paced weight stream
+#endif
         }
     };
     uint32_t* box = a.sync + SYNC_BOX_O + (size_t)bid * O3V_SYNC_STRIDE;

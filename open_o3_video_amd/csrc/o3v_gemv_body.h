@@ -2,6 +2,7 @@
 // the role-fused decode launch of o3v_fused.hip: both instantiate THIS code, so their results are bit-identical.
 #pragma once
 #include "o3v_common.h"
+#include "o3v_handoff.h"
 
 #define EPI_NONE 0
 #define EPI_RESIDUAL 1
@@ -42,7 +43,7 @@ struct RopeArgs {  // EPI_QKVROPE destinations (one token per row m, cache slot 
     int slot, Hq, Hkv, D, Tmax, cs_stride, cs_off;
 };
 
-// PUB (EPI_QKVROPE only): the outputs (q, new K/V row) are handed to other workgroups of the SAME launch
+// PUB: the outputs (q and the new K/V row; a SwiGLU / plain output row) are handed to other workgroups of the SAME launch
 // (o3v_fused.hip): they are stored write-through (sc1) so that a drained store is visible beyond this XCD's L2.
 template <bool PUB>
 __device__ __forceinline__ void gemv_store_bf16(bf16_t* p, bf16_t v) {
@@ -132,6 +133,16 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
     // weight loads of one trip (U steps x R rows, 16 B per lane each): issued as early as possible
     u32x4 wv[U][R];
     u32x4 xg[NORM ? 1 : U][NORM ? 1 : M];  // un-normalised x comes from global memory (L2): fetched one trip ahead, with the weights
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const int cc = c < c_end ? c : c_begin;
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                xg[NORM ? 0 : u][NORM ? 0 : m] = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
+        }
+    };
     auto load_w = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -143,11 +154,8 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 wv[u][r] = __builtin_nontemporal_load(wp[r] + cc);
                 if (!in) wv[u][r] = (u32x4){0, 0, 0, 0};
             }
-            if (!NORM) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) xg[u][m] = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
-            }
         }
+        if (!NORM) load_x(c0);
     };
 
     if (NORM) {
@@ -323,7 +331,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const float g = rbf(acc[2 * r][m] + bg), u = rbf(acc[2 * r + 1][m] + bu);
-                out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
+                gemv_store_bf16<PUB>(out + (size_t)m * ldo + no, f2bf(rbf(silu_f(g)) * u));
             }
         }
     } else {
@@ -337,7 +345,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 float v = acc[r][m] + bv;
                 if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[EPI == EPI_RESIDUAL ? r : 0][EPI == EPI_RESIDUAL ? m : 0];
                 if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
-                out[(size_t)m * ldo + n] = f2bf(v);
+                gemv_store_bf16<PUB>(out + (size_t)m * ldo + n, f2bf(v));
             }
         }
     }

@@ -765,3 +765,4 @@ def test_decode_attn_block_fused_equals_three_launches(dev, Hq, Hkv, H, ctx, Tma
         assert torch.equal(k2.view(torch.int16), k1.view(torch.int16)) and torch.equal(v2.view(torch.int16), v1.view(torch.int16))
         assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
+

@@ -62,7 +62,7 @@ def main():
     part_o = torch.empty(Hq * 64 * D, dtype=torch.float32, device=dev)
     part_ml = torch.empty(Hq * 64 * 2, dtype=torch.float32, device=dev)
     sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
-    epoch = [0]
+    epoch = [0, 0]   # launches made on `sync`: attention block, MLP block
     TMO = _lib.SYNC_TMO_BYTE
     P = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -128,9 +128,10 @@ def main():
     roles = (("qkv", 0, nb_qkv), ("attn", nb_qkv, nb_qkv + nb_attn), ("o_proj", nb_qkv + nb_attn, grid))
     print(f"grid {grid}: qkv {nb_qkv} attn {nb_attn} o {grid - nb_qkv - nb_attn}; times in us from the first workgroup's start")
     for knob, what in ((0, "full"), (1, "q/k/v role alone"), (2, "q/k/v + attention (o_proj role exits)"),
-                       (4, "no K/V request ahead of the wait"), (8, "o_proj weights after the wait"), (12, "neither")):
+                       (4, "no K/V request ahead of the wait"), (8, "o_proj weights after the wait"), (12, "neither"),
+                       (32, "o_proj weight stream paced: 1 x s_sleep 16 per step"), (64, "paced 2x"), (128, "paced 4x")):
         lib.o3v_fused_set_knob(knob)
-        tl = timeit(step_fused, args.steps) if knob in (0, 4, 8, 12) else float("nan")
+        tl = timeit(step_fused, args.steps) if knob not in (1, 2) else float("nan")
         stamps.zero_()
         lib.o3v_fused_set_stamps(P(stamps))
         step_fused()
@@ -139,7 +140,7 @@ def main():
         code = int(sync[TMO:TMO + 4].view(torch.int32)[0].item())
         print(f"        time-out word {code:#x}")
         sync.zero_()   # an ablation that removes a role leaves the tickets out of step with the epochs: start over
-        epoch[0] = 0
+        epoch[0] = epoch[1] = 0
         t = stamps.cpu().numpy().reshape(grid, 8).astype(np.float64) / 100.0   # 100 MHz -> us
         t0 = t[:, 0][t[:, 0] > 0].min()
 
