@@ -8,9 +8,16 @@ reference's training resolution 224x420 (SURVEY.md section 8 TRAIN-RES; S = 4490
 penalty 1.05 (R:eval/models/model_vllm.py:30).  Weights: seeded random bf16 at true 7B dims (no checkpoints
 offline; throughput does not depend on weight values).  value = generated tokens / wall time, whole job.
 
-Multi-GPU (torchrun, one process per GPU): every rank owns a replica and its own videos (weak scaling, no data-path
-collective -- the eval path shards by independent videos); timing is bracketed by barrier +
-synchronize and reduced with MAX over ranks.
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (open_o3_video_amd/launch.py: one child process per GPU,
+rendezvous on 127.0.0.1; the parent never touches the GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
+Every rank owns a replica and its own videos (weak scaling, no data-path collective -- the eval path shards by
+independent videos); timing is bracketed by barrier + synchronize and reduced with MAX over
+ranks.  `n_gpus` in the result line is torch.distributed's world size; a rank-count mismatch exits non-zero.
+
+Second measured leg (`rollout` in the line; BASELINE config #3, R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:402-742):
+rank r takes prompt r, samples G = 8 completions (top_p 0.95, T 1) behind one ViT pass and one prefill, computes their
+per-token log-probs and the rewards, and the ranks exchange the packed [G, 9+] record with ONE all_gather_into_tensor
+per step (RCCL over xGMI when the backend is nccl) -- the collective is inside the timed region.
 """
 from __future__ import annotations
 
@@ -156,7 +163,120 @@ def kernel_roofline(eng, reps=3):
         pass
     return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=4,KS=1,SWIGLU,NORM> (RMSNorm + LLM gate/up projection, decode)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
+            "traffic": traffic, "traffic_source": "profiles/r01_gemv_pmc.json (rocprofv3 --pmc passes of this kernel on this shape; "
+                                                  "not a counter of this run)" if traffic is not None else None,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
+
+
+def cpu_baseline_config1(new_tokens=32):
+    """BASELINE config #1 timed IN FULL on the host cores: Qwen2.5-VL-3B dims (32 ViT blocks, 36 LLM layers, tied
+    embeddings), 4 frames 364x644 (4784 patches -> 1196 visual tokens), the whole prompt, `new_tokens` greedy decode steps,
+    through oracle/model_ref.py (the same torch-CPU bf16 ops as the HF path).  Nothing is extrapolated."""
+    from oracle import model_ref, index_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixture_models as fm
+    from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict
+    cd = qwen25vl_3b_dict()
+    cfg = O3VConfig.from_dict(cd)
+    g = torch.Generator().manual_seed(0)
+    W_ = {}
+    for name, shape, kind in fm.weight_specs(cd):
+        t = torch.empty(shape, dtype=torch.bfloat16)
+        if kind == "norm":
+            t.fill_(1.0)
+        else:
+            t.normal_(0, 0.02, generator=g)
+        W_[name] = t
+    nf, H, W = 4, 364, 644
+    tpf = (H // 28) * (W // 28)
+    ids = np.asarray([build_prompt(cfg, nf, tpf, nf * (tpf + 15) + 170)], dtype=np.int64)
+    frames = torch.randint(0, 256, (nf, 3, H, W), generator=g, dtype=torch.uint8)
+    mean = np.asarray(index_ref.CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.asarray(index_ref.CLIP_STD, dtype=np.float32)[None, :, None, None]
+    xf = ((frames.numpy().astype(np.float64) / 255.0).astype(np.float32) - mean) / std
+    pv, grid = index_ref.patchify_frames(xf.astype(np.float32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = model_ref.generate(W_, cd, ids, None, torch.from_numpy(pv), grid, new_tokens, dtype=torch.bfloat16,
+                                 pad_token_id=cd["pad_token_id"], eos_token_ids=())
+    dt = time.perf_counter() - t0
+    assert out.shape[1] == ids.shape[1] + new_tokens
+    return {"value": round(new_tokens / dt, 4), "unit": "tokens/s (end to end: ViT + prefill + decode)", "wall_s": round(dt, 2),
+            "sample": f"config #1 in full: 3B dims, {nf} frames {H}x{W}, S={ids.shape[1]}, {new_tokens} greedy tokens, nothing scaled"}
+
+
+# reward functions of the rollout leg: the product's own seven (R:src/r1-v/src/open_r1/grpo.py:58-66) on the decoded text
+def _rollout_rewards():
+    from open_o3_video_amd import rewards
+    return [rewards.REWARD_FUNCS[k] for k in rewards.REWARD_FUNCS]
+
+
+def rollout_leg(cfg, eng, ids, pixel_values, grid, dist, dev, G=8, T=768, steps=2, warmup=1):
+    """GSPO rollout steps (BASELINE config #3): rank r's prompt, G sampled completions, log-probs, rewards, ONE all_gather
+    of the packed per-sample record per step -- all inside the timed region."""
+    from open_o3_video_amd.hf_api import Qwen2_5_VLForConditionalGeneration
+    from open_o3_video_amd.rollout import GroupRollout
+    model = Qwen2_5_VLForConditionalGeneration(cfg, eng)
+
+    def decode(comp):   # no tokenizer offline: a deterministic stand-in text per completion
+        return ["<think>" + " ".join(str(int(t)) for t in row[:32]) + "</think><answer>A</answer>" for row in comp.cpu().tolist()]
+
+    ro = GroupRollout(model, _rollout_rewards(), decode, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                      num_generations=G, max_completion_length=T)
+    inputs = dict(input_ids=torch.tensor([ids]), attention_mask=torch.ones(1, len(ids), dtype=torch.long),
+                  pixel_values=pixel_values, image_grid_thw=torch.from_numpy(grid))
+    # one dataset row with every column the seven rewards read (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:455-469, :648-656)
+    example = {"prompt": "p", "task": "temporal-spatial free-form QA", "answer": "<answer>A</answer>", "step_percent": 0.5,
+               "image_size": (420, 224), "image_size_refine": (420, 224), "video_sample_fps": 1.0,
+               "key_frames": [{"idx": 3, "time": 3.0}], "key_items": {"3": {"person": [[10, 10, 100, 100]]}}}
+    n_tok = 0
+    for i in range(warmup):
+        ro.step(inputs, example)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        res = ro.step(inputs, example)
+        n_tok += int(res.completion_mask.sum().item())
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tok = torch.tensor([float(n_tok), dt], device=dev, dtype=torch.float64)
+    world = 1
+    if dist:
+        world = dist.get_world_size()
+        tmax = tok[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tok[:1].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        n_all, dt = float(tsum.item()), float(tmax.item())
+    else:
+        n_all = float(n_tok)
+    return {"G": G, "max_completion_length": T, "steps": steps, "prompts_per_step": world, "tokens_per_s": round(n_all / dt, 1),
+            "ms_per_step": round(dt / steps * 1e3, 1), "record_columns": int(res.rewards_per_func.shape[1]) + 4,
+            "collective": "one all_gather_into_tensor of the packed [G, n_rewards+4] f32 record per step"
+                          + ("" if dist else " (skipped: one rank)")}
+
+
+def launch_check():
+    """CPU-only check of the launch path (tests/test_bench_launch_cpu.py): join the world over gloo, run the rollout's
+    metrics collective on a dummy record, let rank 0 print the world size."""
+    import torch.distributed as dist
+    from open_o3_video_amd import dist as o3v_dist
+    rank, world = o3v_dist.init("gloo")
+    rec = torch.full((8, 11), float(rank))
+    allr = o3v_dist.all_gather_records(rec)
+    assert allr.shape == (8 * world, 11) and float(allr[-1, 0]) == world - 1
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size() if world > 1 else 1, "backend": "gloo"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -171,17 +291,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra 16-videos-per-step throughput measurement")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the GSPO rollout leg (G=8 sampled + log-probs + all_gather)")
+    ap.add_argument("--rollout-tokens", type=int, default=768)
+    ap.add_argument("--launch-check", action="store_true", help="CPU-only: join the world over gloo and print its size")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # started as `python bench.py --gpus N`: become the launcher (no GPU call in this process)
+        from open_o3_video_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]]))
+    if args.launch_check:
+        launch_check()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    world = int(world_env or "1")
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # rehearsal knobs (one-GPU box): O3V_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, O3V_DIST_BACKEND=gloo swaps RCCL out
-    if os.environ.get("O3V_BENCH_ONE_DEVICE") == "1":
+    # rehearsal on a one-GPU box: O3V_BENCH_ONE_DEVICE=1 puts every rank on cuda:0; RCCL refuses two ranks on one device,
+    # so the exchange then runs over gloo and the line says so
+    one_device = os.environ.get("O3V_BENCH_ONE_DEVICE") == "1"
+    if one_device:
         local_rank = 0
-    backend = os.environ.get("O3V_DIST_BACKEND", "nccl")
+    backend = os.environ.get("O3V_DIST_BACKEND", "gloo" if one_device else "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -192,6 +326,8 @@ def main():
         else:
             dist_.init_process_group(backend)
         dist = dist_
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"world size {dist.get_world_size()} != --gpus {args.gpus}")
 
     from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict, qwen25vl_7b_dict
     from open_o3_video_amd.engine import O3VEngine
@@ -200,7 +336,7 @@ def main():
     cfg_dict = qwen25vl_7b_dict() if args.model == "7b" else qwen25vl_3b_dict()
     cfg = O3VConfig.from_dict(cfg_dict)
     dev = torch.device("cuda", local_rank)
-    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=not args.no_batched))
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=not (args.no_batched and args.no_rollout)))
     Hres, Wres = (224, 420) if args.res == "train" else (364, 644)
     tpf = (Hres // 28) * (Wres // 28)
     S = 4490 if args.res == "train" else 10218
@@ -216,6 +352,13 @@ def main():
         return eng.generate([ids], None, frames=videos[i % len(videos)], max_new_tokens=args.new_tokens, eos_token_ids=(),
                             repetition_penalty=1.05, return_margins=False, sync_timings=timings)
 
+    def reduce_max(x):
+        if not dist:
+            return x
+        t = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -229,21 +372,26 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = reduce_max(time.perf_counter() - t0)
     assert out.sequences.shape[1] == S + args.new_tokens
 
     # per-stage breakdown (one extra, untimed, synchronised step)
     stages = step(0, timings=True).timings
 
+    # second measured leg: GSPO rollout with the metrics all_gather inside the timed region
+    roll = None
+    if not args.no_rollout:
+        pv = torch.rand((args.frames * (Hres // 14) * (Wres // 14), 1176), generator=gen, device=dev) * 4 - 2   # processor-shaped pixel_values
+        grid = np.asarray([[1, Hres // 14, Wres // 14]] * args.frames, dtype=np.int64)
+        roll = rollout_leg(cfg, eng, ids, pv, grid, dist, dev, T=args.rollout_tokens)
+        roll["backend"] = backend if dist else None
+        del pv
+
     # extra (not `value`): throughput with 16 videos decoding together per GPU -- the eval path of the reference runs a
     # vLLM engine with max_num_seqs=5 (R:eval/models/model_vllm.py:23), i.e. it batches concurrent requests too.  Decode is
     # weight-bandwidth-bound, so the 16 sequences share every streamed weight byte (MFMA skinny-GEMM path).
     batched = None
-    if not args.no_batched:
+    if not args.no_batched and rank == 0:
         NB = O3VEngine.MAX_ROWS
         vids8 = torch.randint(0, 256, (NB * args.frames, 3, Hres, Wres), generator=gen, dtype=torch.uint8, device=dev)
 
@@ -259,39 +407,48 @@ def main():
         assert o8.sequences.shape == (NB, S + args.new_tokens)
         batched = {"videos_per_step": NB, "tokens_per_s_per_gpu": round(NB * args.new_tokens / tb, 1),
                    "videos_per_min_per_gpu": round(NB / tb * 60.0, 1), "ms_per_step": round(tb * 1e3, 1)}
-    roof = None if args.no_roofline else kernel_roofline(eng)
+    roof = None if (args.no_roofline or rank != 0) else kernel_roofline(eng)
 
     if rank == 0:
-        total_tokens = world * args.steps * args.new_tokens
+        n_gpus = dist.get_world_size() if dist else 1
+        total_tokens = n_gpus * args.steps * args.new_tokens
         ms_per_step = dt / args.steps * 1e3
         tc = cfg.text
         wbytes = sum(eng.w.t[f"l{l}.{k}"].numel() * 2 for l in range(tc.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
         wbytes += eng.w.t["l.head"].numel() * 2
         kv_bytes = 2 * tc.num_hidden_layers * tc.num_key_value_heads * tc.head_dim * 2 * (S + args.new_tokens / 2)
         dec_ms = stages.get("decode_ms", 0.0) / max(1, args.new_tokens)
+        par = f"dp{n_gpus} (replica per GPU, independent videos, no data-path collective in the headline leg)"
+        if dist:
+            par += f"; torch.distributed backend {backend}" + (" -- REHEARSAL: every rank on cuda:0" if one_device else " (RCCL)")
         rec = {
             "metric": "grounded_cot_tokens_per_sec", "value": round(total_tokens / dt, 2), "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{args.model.upper()} dims, {args.frames} frames {Hres}x{Wres} -> "
                                    f"{args.frames * tpf} visual tokens, prompt S={S}, greedy decode {args.new_tokens} new tokens "
                                    f"(EOS suppressed, repetition_penalty 1.05), batch 1 per GPU, random-init bf16 weights",
-                       "parallelism": f"dp{world} (replica per GPU, independent videos, no data-path collective)"},
-            "videos_per_min": round(world * args.steps / dt * 60.0, 2),
+                       "parallelism": par},
+            "videos_per_min": round(n_gpus * args.steps / dt * 60.0, 2),
             "stage_ms": {k: round(v, 2) for k, v in stages.items()},
             "decode_tokens_per_sec_per_gpu": round(1e3 / dec_ms, 1) if dec_ms else None,
             "decode_step_hbm": {"algorithmic_bytes": int(wbytes + kv_bytes), "ms": round(dec_ms, 4),
                                 "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
-                                "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None},
+                                "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None,
+                                "launches_per_layer": 4 if eng.fused_decode else 6},
         }
+        if roll:
+            rec["rollout"] = roll
         if batched:
             rec["batched_videos"] = batched
         if roof:
             rec["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and n_gpus == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg_dict, args.frames, Hres, Wres, S, args.new_tokens)
+            rec["cpu_baseline"]["config1_full"] = cpu_baseline_config1()
         print(json.dumps(rec), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -248,3 +248,38 @@ def test_group_parallel_rollout_two_ranks(need_gpu, golden_dir):
         assert out["mask"] == ref["mask"].tolist() and out["rewards"] == ref["rewards"].tolist()
         assert torch.allclose(torch.tensor(out["lp"]) * m, ref["lp"] * m, atol=1e-5)
         assert torch.allclose(torch.tensor(out["adv"]), ref["adv"], atol=1e-5) and abs(out["loss"] - ref["loss"]) < 1e-5
+
+
+def _nccl_one_rank(port, q):
+    import torch.distributed as td
+    from open_o3_video_amd import dist as od
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    td.init_process_group("nccl", device_id=torch.device("cuda", 0))   # RCCL communicator on the one GPU of the box
+    rec = torch.arange(8 * 11, dtype=torch.float32, device="cuda").view(8, 11)
+    out = torch.empty_like(rec)
+    td.all_gather_into_tensor(out, rec)            # the rollout's metrics collective, through RCCL
+    t = torch.tensor([3.5], device="cuda", dtype=torch.float64)
+    td.all_reduce(t, op=td.ReduceOp.MAX)           # the bench's MAX-over-ranks reduction
+    td.barrier()
+    q.put((td.get_backend(), bool(torch.equal(out, rec)), float(t.item())))
+    td.destroy_process_group()
+
+
+def test_rccl_backend_collectives_one_rank(need_gpu):
+    """backend "nccl" (= RCCL on ROCm) with the device_id init bench.py and dist.init use: communicator creation,
+    all_gather_into_tensor, all_reduce(MAX) and barrier on the box's one GPU (RCCL refuses two ranks on one device, so the
+    multi-rank RCCL run is the driver's 8-GPU job)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank, args=(port, q))
+    p.start()
+    backend, same, mx = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert backend == "nccl" and same and mx == 3.5
