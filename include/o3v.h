@@ -10,7 +10,8 @@
  *
  * Conventions: plain pointers + sizes, no torch types.  All device buffers are caller-allocated, bf16 is a raw
  * uint16 pattern, every call only ENQUEUES work on `stream` (no sync, no allocation, graph-capturable) and returns
- * 0 or a negative O3V_ERR_* code; nothing throws.  Thread-safe for distinct streams.
+ * 0 or a negative O3V_ERR_* code; nothing throws.  Thread-safe for distinct streams: the library keeps no mutable state
+ * (every tunable travels in an argument or a descriptor; the only statics are occupancy figures queried once).
  */
 #ifndef O3V_H
 #define O3V_H
@@ -25,7 +26,7 @@ typedef struct ihipStream_t* o3v_stream_t; /* hipStream_t */
 
 #define O3V_OK 0
 #define O3V_ERR_ARG (-1)    /* null pointer / negative size / inconsistent arguments */
-#define O3V_ERR_SHAPE (-2)  /* shape not supported by the kernels (alignment, head_dim, M > 8 for gemv ...) */
+#define O3V_ERR_SHAPE (-2)  /* shape not supported by the kernels (alignment, head_dim, M > 16 for the decode linears ...) */
 #define O3V_ERR_LAUNCH (-3) /* HIP reported a launch failure */
 #define O3V_ERR_WORKSPACE (-4)
 
@@ -74,30 +75,31 @@ int o3v_resize_bicubic_aa(const void* src, int is_u8, float* tmp, float* dst, in
 int o3v_crop_resize_bilinear(const void* frames, const int* boxes, void* out, int n, int T, int H, int W,
                              o3v_stream_t stream);
 
-/* Cache prefetch hint: stream `bytes` at `ptr` through `blocks` workgroups (result discarded) so the next reader finds
- * them in L2 / Infinity Cache; meant for a side stream beside a latency-bound kernel. */
-int o3v_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, o3v_stream_t stream);
+/* 128-bit content hash of `bytes` bytes at `data` (8-byte aligned) into out[2] (u64, ZEROED by the caller): cache keys of
+ * the visual-token / prefix-K/V caches.  Order-independent sums of mixed words: exact and reproducible. */
+int o3v_content_hash128(const void* data, size_t bytes, unsigned long long* out, o3v_stream_t stream);
 
 /* ---- GEMMs ------------------------------------------------------------------------------------------------ */
 /* nn.Linear: out[M,N] = epi(A[M,K] . W[N,K]^T + bias); K % 64 == 0.  MFMA path (ViT, merger, prefill). */
 int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
-/* Tile choice of o3v_gemm_bf16: 0 = per shape (default), 128 or 256 = force that kernel (tests and A/B measurements). */
-int o3v_gemm_set_tile(int tile);
+/* the same with the tile forced: 0 = per shape (what o3v_gemm_bf16 does), 128 or 256 (tests and A/B measurements; both
+ * kernels give bit-identical results).  The model-level entries take the choice from their descriptor's gemm_tile. */
+int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
+                       int ldw, int ldo, int ldr, int epilogue, int tile, o3v_stream_t stream);
 /* o3v_gemm_bf16 for row counts too small to fill the chip with 128x128 output tiles (a prompt suffix behind a cached
  * prefix: 9..128 rows): K split over `splits` blocks per tile, fp32 partials in `workspace` (splits*M*N floats), reduced
  * in split order.  Epilogues NONE / RESIDUAL / GELU. */
 int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                          int lda, int ldw, int ldo, int ldr, int epilogue, int splits, float* workspace, size_t ws_bytes,
                          o3v_stream_t stream);
-/* same contract for M <= 8: weight-streaming GEMV (decode). */
+/* same contract for M <= 16 rows (decode): weight-streaming GEMV up to 3 rows, matrix-core skinny GEMM from 4 rows on
+ * (9..16 rows need K % 32 == 0 and N % 16 == 0). */
 int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int ldx,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 
-/* A/B switch of the M == 1 GEMV's CU-balanced workgroup sizes (default on; 0 = always four waves per workgroup). */
-int o3v_gemv_set_balanced(int on);
-
-/* RMSNorm (TF:65-79) fused into the projection that consumes it: out = epi(rmsnorm(X; norm_w, eps) . W^T + bias), M <= 8.
+/* RMSNorm (TF:65-79) fused into the projection that consumes it: out = epi(rmsnorm(X; norm_w, eps) . W^T + bias), M <= 16
+ * (the normalised rows are staged in LDS: M * (2 K + 16) bytes <= 144 KiB).
  * Removes one launch per q/k/v, gate/up and lm_head projection of a decode step. */
 int o3v_gemv_norm_bf16(const void* X, const void* norm_w, float eps, const void* W, const void* bias, const void* res,
                        void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
@@ -157,7 +159,7 @@ int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
  * TF:generation/utils.py:2894-2929, TF:generation/logits_process.py:404-414 */
-#define O3V_SAMPLE_SCRATCH_FLOATS 24576 /* per-row accumulators of o3v_sample_top_p (histograms, slice maxima / masses) */
+#define O3V_SAMPLE_SCRATCH_FLOATS 40960 /* per-row accumulators of o3v_sample_top_k_top_p (histograms, slice maxima / masses) */
 int o3v_sample_greedy(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* margins,
                       const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, int step,
                       int out_stride, float* scratch /* f32[B*256] */, o3v_stream_t stream);
@@ -171,6 +173,12 @@ int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished
                      const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty, float temperature,
                      float top_p, uint64_t seed, const int* row_id, int step, int out_stride,
                      float* scratch /* f32[B * O3V_SAMPLE_SCRATCH_FLOATS], 8-byte aligned */, o3v_stream_t stream);
+/* the same with TopKLogitsWarper (TF:logits_process.py:590-594) between temperature and top-p: scores below the k-th
+ * largest are removed (ties with it stay), top-p then acts on the softmax over what is left.  top_k == 0: no top-k. */
+int o3v_sample_top_k_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids, float* chosen_logprob,
+                           const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl, float rep_penalty,
+                           float temperature, int top_k, float top_p, uint64_t seed, const int* row_id, int step,
+                           int out_stride, float* scratch, o3v_stream_t stream);
 int o3v_mark_seen(const int* ids, void* seen, int B, int S, int V, o3v_stream_t stream);
 /* _get_per_token_logps, R:grpo_trainer.py:371-384: out[r] = log_softmax(logits[r])[target[r]] */
 int o3v_logprob_gather(const void* logits, const int* target, float* out, int R, int V, int ldl, o3v_stream_t stream);
@@ -190,6 +198,7 @@ typedef struct {
     const void* patch_w;           /* [hidden, patch_k_pad] (Conv3d weight flattened, zero pad cols)  TF:99-122 */
     const o3v_vit_block_w* blocks; /* [depth] */
     const void *ln_q, *m0_w, *m0_b, *m2_w, *m2_b; /* merger TF:137-150 */
+    int gemm_tile;                 /* 0 = per shape; 128 / 256 = force that GEMM kernel (tests) */
 } o3v_vit_desc;
 
 typedef struct {
@@ -210,6 +219,7 @@ typedef struct {
     const void* final_norm;      /* [H] */
     const void* lm_head;         /* [vocab, H] (== embed when tied) */
     const void* lm_head_p;       /* optional fragment-major copy of lm_head */
+    int gemm_tile;               /* 0 = per shape; 128 / 256 = force that GEMM kernel in the prefill (tests) */
 } o3v_llm_desc;
 
 size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P);
@@ -253,13 +263,12 @@ typedef struct {
     float *part_o, *part_ml;     /* decode-attention split buffers */
     float *sample_scratch;       /* f32 [B, O3V_SAMPLE_SCRATCH_FLOATS] when sampling, f32 [B,256] for greedy */
     void *workspace; size_t ws_bytes;
-    o3v_stream_t side_stream;    /* optional: weight prefetch runs here beside the decode attention (NULL = off) */
-    size_t prefetch_bytes;       /* bytes of the next projections' weights to pull on-die per layer */
     int group;                   /* > 1: rows g*group..g*group+group-1 share their first S keys -> o3v_attn_decode_group
                                     (nsplit is then the prefix split count; part_o/part_ml hold 64 splits) */
     uint32_t *sync;              /* optional: o3v_decode_sync_bytes() bytes, 128-byte aligned, zeroed by the caller before the
                                     first step of a generate call.  Non-NULL selects the one-launch attention block
                                     (o3v_decode_attn_block) where its shapes allow (B == 1) */
+    int top_k;                   /* sampling only: TopKLogitsWarper's k, 0 = off */
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

@@ -24,7 +24,7 @@ class VitBlockW(C.Structure):
 class VitDesc(C.Structure):
     _fields_ = [("depth", i32), ("hidden", i32), ("heads", i32), ("inter_pad", i32), ("out_hidden", i32),
                 ("patch_k_pad", i32), ("merge_unit", i32), ("fullatt_mask", u64), ("patch_w", vp),
-                ("blocks", C.POINTER(VitBlockW)), ("ln_q", vp), ("m0_w", vp), ("m0_b", vp), ("m2_w", vp), ("m2_b", vp)]
+                ("blocks", C.POINTER(VitBlockW)), ("ln_q", vp), ("m0_w", vp), ("m0_b", vp), ("m2_w", vp), ("m2_b", vp), ("gemm_tile", i32)]
 
 
 class LlmLayerW(C.Structure):
@@ -34,7 +34,7 @@ class LlmLayerW(C.Structure):
 class LlmDesc(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
                 ("vocab", i32), ("rms_eps", f32), ("embed", vp), ("layer", C.POINTER(LlmLayerW)), ("final_norm", vp),
-                ("lm_head", vp), ("lm_head_p", vp)]
+                ("lm_head", vp), ("lm_head_p", vp), ("gemm_tile", i32)]
 
 
 class DecodeState(C.Structure):
@@ -43,7 +43,7 @@ class DecodeState(C.Structure):
                 ("x", vp), ("kcache", vp), ("vcache", vp), ("cosT", vp), ("sinT", vp), ("logits", vp), ("seen", vp),
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
-                ("ws_bytes", sz), ("side_stream", vp), ("prefetch_bytes", sz), ("group", i32), ("sync", vp)]
+                ("ws_bytes", sz), ("group", i32), ("sync", vp), ("top_k", i32)]
 
 
 # name -> argtypes (return type int unless listed in _RET)
@@ -58,13 +58,12 @@ SIGNATURES = {
     "o3v_embed_tokens": [vp, vp, vp, i32, i32, vp],
     "o3v_cast_pad_f32_bf16": [vp, vp, i32, i32, i32, vp],
     "o3v_patchify": [vp, i32, vp, i32, i32, i32, i32, fp, fp, vp],
-    "o3v_prefetch": [vp, sz, i32, vp, vp],
+    "o3v_content_hash128": [vp, sz, vp, vp],
     "o3v_gemm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
     "o3v_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
-    "o3v_gemm_set_tile": [i32],
-    "o3v_gemv_set_balanced": [i32],
+    "o3v_gemm_bf16_tile": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemm_bf16_splitk": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp],
     "o3v_resize_bicubic_aa": [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp],
     "o3v_crop_resize_bilinear": [vp, vp, vp, i32, i32, i32, i32, vp],
@@ -79,6 +78,7 @@ SIGNATURES = {
     "o3v_linear_decode": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_norm_bf16": [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_sample_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, u64, vp, i32, i32, vp, vp],
+    "o3v_sample_top_k_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, i32, f32, u64, vp, i32, i32, vp, vp],
     "o3v_mark_seen": [vp, vp, i32, i32, i32, vp],
     "o3v_logprob_gather": [vp, vp, vp, i32, i32, i32, vp],
     "o3v_vit_workspace_bytes": [C.POINTER(VitDesc), i32],
@@ -91,7 +91,7 @@ SIGNATURES = {
 _RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
 
 SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
-SAMPLE_SCRATCH_FLOATS = 24576   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h
+SAMPLE_SCRATCH_FLOATS = 40960   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h
 
 _lib = None
 
@@ -115,7 +115,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
             fn.argtypes = args
             fn.restype = _RET.get(name, i32)
-        if lib.o3v_abi_version() != 2:
+        if lib.o3v_abi_version() != 3:
             raise O3VError("libo3v_hip.so ABI version mismatch")
         _lib = lib
     return _lib

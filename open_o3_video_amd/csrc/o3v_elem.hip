@@ -768,26 +768,52 @@ extern "C" int o3v_logprob_gather(const void* logits, const int* target, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// L2 / Infinity-Cache prefetch: stream `bytes` of a weight image through a few CUs so that the kernel which reads it
-// next finds it on-die.  Launched on a side stream while the (latency-bound, HBM-idle) decode attention runs.
-// Purely a hint: no data dependency, the result is discarded.
+// 128-bit content hash of a device buffer (cache keys of the visual-token / prefix-K/V caches: two clips must never share
+// a key by accident).  h = (sum_i mix(w_i + c1 i), sum_i mix(w_i * c2 ^ (i + c3))) over the 8-byte words w_i, mix =
+// splitmix64's finaliser: sums commute, so the blocks combine with integer atomics in any order; the tail bytes and the
+// length enter as extra words.  Not cryptographic; a chance collision is ~2^-128.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
-    unsigned acc = 0;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
-    }
-    for (; i < n16; i += stride) acc ^= p[i][0];
-    if (acc == 0x9E3779B9u && sink) *sink = acc;  // practically never true: keeps the loads alive
+namespace {
+__device__ __forceinline__ unsigned long long hmix64(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
 }
+__global__ __launch_bounds__(256) void content_hash_kernel(const unsigned long long* __restrict__ p, size_t nwords,
+                                                            const unsigned char* __restrict__ tail, int ntail, size_t nbytes,
+                                                            unsigned long long* __restrict__ out) {
+    unsigned long long h1 = 0, h2 = 0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) {
+        const unsigned long long w = p[i];
+        h1 += hmix64(w + 0x9E3779B97F4A7C15ull * (i + 1));
+        h2 += hmix64((w * 0xD1B54A32D192ED03ull) ^ (i + 0x2545F4914F6CDD1Dull));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < ntail; ++k) t |= (unsigned long long)tail[k] << (8 * k);
+        h1 += hmix64(t + 0x9E3779B97F4A7C15ull * (nwords + 1)) + hmix64(nbytes ^ 0xA0761D6478BD642Full);
+        h2 += hmix64((t * 0xD1B54A32D192ED03ull) ^ (nwords + 0x2545F4914F6CDD1Dull)) + hmix64(nbytes * 0xE7037ED1A0B428DBull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        h1 += ((unsigned long long)__shfl_xor((unsigned)(h1 >> 32), o, 64) << 32) | __shfl_xor((unsigned)h1, o, 64);
+        h2 += ((unsigned long long)__shfl_xor((unsigned)(h2 >> 32), o, 64) << 32) | __shfl_xor((unsigned)h2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, h1);
+        atomicAdd(out + 1, h2);
+    }
+}
+}  // namespace
 
-extern "C" int o3v_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, hipStream_t stream) {
-    if (!ptr || blocks <= 0) return O3V_ERR_ARG;
-    if (bytes < 16) return O3V_OK;
-    O3V_KLAUNCH(prefetch_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4*)ptr, bytes / 16, (unsigned*)sink);
+// out: 2 x u64, zeroed by the caller before the call; data 8-byte aligned
+extern "C" int o3v_content_hash128(const void* data, size_t bytes, unsigned long long* out, hipStream_t stream) {
+    if (!data || !out || (reinterpret_cast<uintptr_t>(data) & 7)) return O3V_ERR_ARG;
+    const size_t nwords = bytes / 8;
+    int blocks = (int)((nwords + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    O3V_KLAUNCH(content_hash_kernel, dim3(blocks), dim3(256), 0, stream, (const unsigned long long*)data, nwords,
+                (const unsigned char*)data + nwords * 8, (int)(bytes - nwords * 8), bytes, out);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

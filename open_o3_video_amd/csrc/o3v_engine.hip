@@ -32,7 +32,7 @@ constexpr int SPLITK_MAX_N = 8192;
 // nn.Linear for any row count: MFMA GEMM above 8 rows, weight-streaming GEMV (in groups of 8 rows) otherwise.
 // splitk_ws (optional, SPLITK floats): lets a 9..128-row GEMM with few output tiles split K over more blocks.
 int linear(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
-           int ldo, int ldr, int epi, o3v_stream_t s, float* splitk_ws = nullptr, size_t splitk_bytes = 0) {
+           int ldo, int ldr, int epi, o3v_stream_t s, float* splitk_ws = nullptr, size_t splitk_bytes = 0, int tile = 0) {
     if (M > 8) {
         const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
         if (splitk_ws && M <= SPLITK_MAX_ROWS && N <= SPLITK_MAX_N && tiles < 128 && epi != O3V_EPI_SWIGLU) {
@@ -43,14 +43,14 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
                 return o3v_gemm_bf16_splitk(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, splits, splitk_ws,
                                             splitk_bytes, s);
         }
-        return o3v_gemm_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
+        return o3v_gemm_bf16_tile(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, tile, s);
     }
     return o3v_gemv_bf16(A, W, bias, res, out, M, N, K, lda, K, ldo, ldr, epi, s);
 }
 
 }  // namespace
 
-extern "C" int o3v_abi_version(void) { return 2; }
+extern "C" int o3v_abi_version(void) { return 3; }
 
 // ------------------------------------------------------------------------------------------------ ViT
 extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
@@ -89,29 +89,29 @@ extern "C" int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P,
     const float scale = 1.0f / sqrtf((float)D);
 
     // patch embed (Conv3d k=s == GEMM over flattened patches), then window order at merge-unit granularity
-    TRY(o3v_gemm_bf16(pixels, d->patch_w, nullptr, nullptr, h, P, hid, d->patch_k_pad, d->patch_k_pad, d->patch_k_pad, hid,
-                      0, O3V_EPI_NONE, s));
+    TRY(o3v_gemm_bf16_tile(pixels, d->patch_w, nullptr, nullptr, h, P, hid, d->patch_k_pad, d->patch_k_pad, d->patch_k_pad, hid,
+                      0, O3V_EPI_NONE, d->gemm_tile, s));
     TRY(o3v_gather_rows(h, win_idx, x, Pm, unit * hid * 2, s));
 
     for (int i = 0; i < d->depth; ++i) {
         const o3v_vit_block_w& w = d->blocks[i];
         const bool full = (d->fullatt_mask >> i) & 1;
         TRY(o3v_rmsnorm(x, w.norm1, h, P, hid, hid, hid, 1e-6f, s));
-        TRY(o3v_gemm_bf16(h, w.qkv_w, w.qkv_b, nullptr, qkv, P, 3 * hid, hid, hid, hid, 3 * hid, 0, O3V_EPI_NONE, s));
+        TRY(o3v_gemm_bf16_tile(h, w.qkv_w, w.qkv_b, nullptr, qkv, P, 3 * hid, hid, hid, hid, 3 * hid, 0, O3V_EPI_NONE, d->gemm_tile, s));
         TRY(o3v_vit_rope(qkv, cosT, sinT, P, H, D, s));
         TRY(o3v_attn_tiles(qkv, qkv + (size_t)hid * 2, qkv + (size_t)2 * hid * 2, att, full ? tiles_full : tiles_win,
                            full ? n_tiles_full : n_tiles_win, 64, H, 1, D, 3L * hid, 3L * hid, D, 0, 3L * hid, D, 0, hid, scale,
                            s));
-        TRY(o3v_gemm_bf16(att, w.proj_w, w.proj_b, x, x, P, hid, hid, hid, hid, hid, hid, O3V_EPI_RESIDUAL, s));
+        TRY(o3v_gemm_bf16_tile(att, w.proj_w, w.proj_b, x, x, P, hid, hid, hid, hid, hid, hid, O3V_EPI_RESIDUAL, d->gemm_tile, s));
         TRY(o3v_rmsnorm(x, w.norm2, h, P, hid, hid, hid, 1e-6f, s));
-        TRY(o3v_gemm_bf16(h, w.gu_w, w.gu_b, nullptr, mlp, P, 2 * ip, hid, hid, hid, ip, 0, O3V_EPI_SWIGLU, s));
-        TRY(o3v_gemm_bf16(mlp, w.down_w, w.down_b, x, x, P, hid, ip, ip, ip, hid, hid, O3V_EPI_RESIDUAL, s));
+        TRY(o3v_gemm_bf16_tile(h, w.gu_w, w.gu_b, nullptr, mlp, P, 2 * ip, hid, hid, hid, ip, 0, O3V_EPI_SWIGLU, d->gemm_tile, s));
+        TRY(o3v_gemm_bf16_tile(mlp, w.down_w, w.down_b, x, x, P, hid, ip, ip, ip, hid, hid, O3V_EPI_RESIDUAL, d->gemm_tile, s));
     }
     // merger: RMSNorm -> [P/4, 4*hid] -> Linear+GELU -> Linear -> original token order
     TRY(o3v_rmsnorm(x, d->ln_q, h, P, hid, hid, hid, 1e-6f, s));
     const int mh = hid * unit;
-    TRY(linear(h, d->m0_w, d->m0_b, nullptr, m1, Pm, mh, mh, mh, mh, 0, O3V_EPI_GELU, s));
-    TRY(linear(m1, d->m2_w, d->m2_b, nullptr, m2, Pm, d->out_hidden, mh, mh, d->out_hidden, 0, O3V_EPI_NONE, s));
+    TRY(linear(h, d->m0_w, d->m0_b, nullptr, m1, Pm, mh, mh, mh, mh, 0, O3V_EPI_GELU, s, nullptr, 0, d->gemm_tile));
+    TRY(linear(m1, d->m2_w, d->m2_b, nullptr, m2, Pm, d->out_hidden, mh, mh, d->out_hidden, 0, O3V_EPI_NONE, s, nullptr, 0, d->gemm_tile));
     TRY(o3v_gather_rows(m2, rev_idx, out, Pm, d->out_hidden * 2, s));
     return O3V_OK;
 }
@@ -184,14 +184,14 @@ extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT,
         char* kc = (char*)kcache + l * layer_stride;
         char* vc = (char*)vcache + l * layer_stride;
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
-        TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes));
+        TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
         TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
                            (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
-        TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes));
+        TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));
-        TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s));
-        TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes));
+        TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s, nullptr, 0, d->gemm_tile));
+        TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
     }
     return O3V_OK;
 }
@@ -235,24 +235,13 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         return O3V_ERR_WORKSPACE;
     const float scale = 1.0f / sqrtf((float)D);
     const size_t layer_stride = (size_t)B * Hkv * st->Tmax * D * 2;
-    // optional side stream: while the latency-bound attention of layer l runs (HBM nearly idle), pull the weights the
-    // next two projections will stream (o_proj, head of gate/up) into the Infinity Cache
-    static hipEvent_t ev_ring[8];
-    static bool ev_init = false;
-    if (st->side_stream && !ev_init) {
-        for (auto& e : ev_ring)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return O3V_ERR_LAUNCH;
-        ev_init = true;
-    }
-    int ev_i = 0;
-    const size_t o_bytes = (size_t)H * QD * 2, gu_bytes = (size_t)2 * I * H * 2;
     // B >= 4 rows run on the matrix-core linears, which stage the normalised x of a fused RMSNorm in LDS (57 KB at B=8, 115 KB
     // at B=16: two blocks, then one, per CU).  With a separate 3 us norm launch the linears are LDS-free: gate/up 54 -> 44 us
     // at B=8, 75 -> 50 us at B=16 (profiles/r01_m8_linear.txt).  Whole step, 7B: B=4 3.56 -> 3.61 ms (worse: two more
     // launches per layer), B=8 4.04 -> 3.97, B=16 5.63 -> 5.25: taken from B=8 on.
     const bool norm_apart = B >= 8;
     // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
-    bool fused = st->sync && B == 1 && st->group <= 1 && !(st->side_stream && st->prefetch_bytes) && st->nsplit > 0;
+    bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
     int step = step0;
     // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
     auto attention_half = [&](int l) -> int {
@@ -267,16 +256,6 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
                                        kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         }
-        if (st->side_stream && st->prefetch_bytes) {
-            hipEvent_t ev = ev_ring[ev_i++ & 7];
-            if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(st->side_stream, ev, 0) != hipSuccess)
-                return O3V_ERR_LAUNCH;
-            const size_t pb = st->prefetch_bytes;
-            TRY(o3v_prefetch(lw.o_w, pb < o_bytes ? pb : o_bytes, 48, st->part_ml, st->side_stream));
-            if (pb > o_bytes)
-                TRY(o3v_prefetch(lw.gu_w, (pb - o_bytes) < gu_bytes ? (pb - o_bytes) : gu_bytes, 48, st->part_ml,
-                                 st->side_stream));
-        }
         if (st->group > 1)  // the rows of a group share the prompt K/V: read it once per group
             TRY(o3v_attn_decode_group(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D, st->S,
                                       st->S + step + 1, st->Tmax, st->nsplit, scale, s));
@@ -289,9 +268,9 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     for (int i = 0; i < n_steps; ++i) {
         step = step0 + i;
         if (st->do_sample)
-            TRY(o3v_sample_top_p(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
-                                 st->n_eos, st->pad_id, B, V, V, st->rep_penalty, st->temperature, st->top_p, st->seed,
-                                 st->row_id, step, st->Tnew, st->sample_scratch, s));
+            TRY(o3v_sample_top_k_top_p(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
+                                       st->n_eos, st->pad_id, B, V, V, st->rep_penalty, st->temperature, st->top_k, st->top_p,
+                                       st->seed, st->row_id, step, st->Tnew, st->sample_scratch, s));
         else  // greedy: the chosen token's embedding row is gathered by the sampler's last stage
             TRY(o3v_sample_greedy_embed(st->logits, st->seen, st->cur_tok, st->finished, st->out_ids, st->margins, st->eos_ids,
                                         st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, st->sample_scratch,

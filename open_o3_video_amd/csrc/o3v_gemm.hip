@@ -631,8 +631,6 @@ struct GemvArgs {
     bool packed;  // W points at the MFMA-fragment-major image (M >= 2 path only)
 };
 
-static int g_gemv_unbalanced = 0;  // A/B switch (o3v_gemv_set_balanced): 1 = always four waves per workgroup
-
 template <int M, int R, int KS, bool NORM, int NW = 4>
 int launch_gemv(const GemvArgs& a) {
     const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : (a.epi == EPI_QKVROPE ? 1 : R);
@@ -676,7 +674,7 @@ int launch_gemv_balanced(const GemvArgs& a) {
         constexpr int CUS = 256;
         const int groups = (a.epi == EPI_QKVROPE) ? a.N / 2 : (a.N + 1) / 2;  // waves per K slice
         const int waves = groups * KS;
-        if (waves % CUS == 0 && !g_gemv_unbalanced) {
+        if (waves % CUS == 0) {
             const int per_cu = waves / CUS;
             if constexpr (KS == 1) {
                 switch (per_cu) {
@@ -775,23 +773,14 @@ extern "C" int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bi
     return O3V_OK;
 }
 
-extern "C" int o3v_gemv_set_balanced(int on) {
-    g_gemv_unbalanced = on ? 0 : 1;
-    return O3V_OK;
-}
-
-static int g_gemm_tile = 0;  // 0: choose per shape; 128 / 256: force (tests, A/B runs)
-extern "C" int o3v_gemm_set_tile(int tile) {
-    g_gemm_tile = (tile == 128 || tile == 256) ? tile : 0;
-    return O3V_OK;
-}
 
 // fraction of the chip's block slots a grid of `tiles` blocks keeps busy over its ceil(tiles/slots) rounds
 static inline float fill_eff(int tiles, int slots) { return (float)tiles / (float)(((tiles + slots - 1) / slots) * slots); }
 
-extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
-                             int lda, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {
-    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
+// tile: 0 = choose per shape, 128 / 256 = force that kernel (tests, A/B measurements; both give bit-identical results)
+extern "C" int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
+                                  int lda, int ldw, int ldo, int ldr, int epilogue, int tile, hipStream_t stream) {
+    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || (tile != 0 && tile != 128 && tile != 256)) return O3V_ERR_ARG;
     if ((K % BK) || (lda & 7) || (ldw & 7)) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
@@ -802,7 +791,7 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
     constexpr float O3V_GEMM256_GAIN = 1.3f;  // full-grid speed ratio of the two kernels (profiles/r01_gemm_tile_ab.txt)
     const float use128 = fill_eff(tiles_m * tiles_n, 512) * ((float)M * N / ((float)tiles_m * BM * (float)tiles_n * BN));
     const float use256 = O3V_GEMM256_GAIN * fill_eff(t2m * t2n, 256) * ((float)M * N / ((float)t2m * BM2 * (float)t2n * BM2));
-    const bool big = g_gemm_tile ? g_gemm_tile == 256 : (M >= 1024 && N >= 1024 && use256 > use128);
+    const bool big = tile ? tile == 256 : (M >= 1024 && N >= 1024 && use256 > use128);
     if (big) {
         dim3 grid(t2m * t2n), block(512);
         const size_t shmem = 8 * 64 * 68 * 4;  // max(2 stages x (A + B) = 128 KiB, epilogue staging 8 waves x 64 x 68 f32)
@@ -835,6 +824,11 @@ extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, con
 #undef O3V_GM
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
+                             int lda, int ldw, int ldo, int ldr, int epilogue, hipStream_t stream) {
+    return o3v_gemm_bf16_tile(A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldr, epilogue, 0, stream);
 }
 
 template <int EPI, bool NORM, int KS, bool PACKED>

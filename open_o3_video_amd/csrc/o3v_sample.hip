@@ -1,5 +1,7 @@
-// Rollout sampler: repetition penalty -> temperature -> top-p -> multinomial, 32 blocks per sequence, no sort.  Restates TF:generation/logits_process.py:404-414 (penalty), :301-303 (temperature),
-// :527-539 (top-p: drop the ascending-sorted prefix whose cumulative probability is <= 1-top_p, keep >= 1)
+// Rollout sampler: repetition penalty -> temperature -> top-k -> top-p -> multinomial, 32 blocks per sequence, no sort.
+// Restates TF:generation/logits_process.py:404-414 (penalty), :301-303 (temperature), :590-594 (top-k: drop every score
+// below the k-th largest; ties with it stay), :527-539 (top-p over what top-k kept: drop the ascending-sorted prefix whose
+// cumulative probability is <= 1-top_p, keep >= 1)
 // and TF:generation/utils.py:2921-2923 (softmax -> multinomial) as used by the GSPO rollout
 // (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313: do_sample, top_p 0.95, temperature 1).
 //
@@ -8,6 +10,8 @@
 // (e = exp(s - max) <= 1), so every sum -- the normaliser, the radix-select histograms, the draw -- is an integer sum:
 // exact and independent of the order the atomics land in, hence reproducible.
 //   pass A  max of the processed scores
+//   top-k   (top_k > 0 only) three count histograms over 12 / 12 / 8 bits of the score's order-preserving key, then one
+//           block per row walks them from the top to the key of the k-th largest score; the passes below skip smaller keys
 //   pass B  z = sum e and the level-0 histogram of mass over the top 12 bits of e (values below 2^-24 are lumped)
 //   pass C/D levels 1 and 2 (12 and 7 more bits) of the radix select for the smallest tau with mass{e <= tau} > (1-top_p) z
 //   pass E  kept mass {e >= tau} per thread, block scan, the thread holding the drawn target walks its own elements
@@ -23,9 +27,11 @@ constexpr float FX_SCALE = 1099511627776.0f;        // 2^40
 typedef unsigned long long u64;
 
 // per-row workspace (u64 units) inside the caller's scratch: O3V_SAMPLE_SCRATCH_FLOATS floats per row
-constexpr int WS_H0 = 0, WS_H1 = 4096, WS_H2 = 8192, WS_BM = 8320, WS_Z = 8352, WS_PREFIX = 8353, WS_PMAX = 8354;
-constexpr int WS_U64 = 8354 + NBLK / 2;             // pmax: NBLK floats
-constexpr int WS_FLOATS = 24576;
+constexpr int WS_H0 = 0, WS_H1 = 4096, WS_H2 = 8192, WS_BM = 8320, WS_Z = 8352, WS_PREFIX = 8353, WS_KTH = 8354;
+constexpr int WS_C0 = 8356, WS_C1 = WS_C0 + 4096, WS_C2 = WS_C1 + 4096;   // top-k count histograms (descending key order)
+constexpr int WS_PMAX = WS_C2 + 256;                                      // everything below is cleared by pass A
+constexpr int WS_U64 = WS_PMAX + NBLK / 2;                                // pmax: NBLK floats
+constexpr int WS_FLOATS = 40960;
 static_assert(WS_U64 * 2 <= WS_FLOATS, "row workspace");
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -146,6 +152,12 @@ __device__ __forceinline__ void for_each_score(const Row& r, int blk, F&& f) {
 
 __device__ __forceinline__ u64 to_fx(float e) { return (u64)(e * FX_SCALE); }
 
+// order-preserving 32-bit key of a score (larger score <=> larger key); kth key 0 keeps everything
+__device__ __forceinline__ unsigned score_key(float s) {
+    const unsigned b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 __device__ __forceinline__ float row_max(const u64* ws) {
     const float* pm = reinterpret_cast<const float*>(ws + WS_PMAX);
     float m = -INFINITY;
@@ -213,6 +225,57 @@ __global__ __launch_bounds__(NT) void sample_max_kernel(const bf16_t* __restrict
     if (threadIdx.x == 0) reinterpret_cast<float*>(ws + WS_PMAX)[blk] = mx;
 }
 
+// top-k, levels 0..2: histogram of COUNTS over 12 / 12 / 8 bits of the inverted key (bin 0 = largest scores), restricted to
+// the bins the earlier levels chose for the k-th largest element
+template <int LVL>
+__global__ __launch_bounds__(NT) void sample_count_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ seen,
+                                                          u64* __restrict__ wsp, int V, int ldl, float rep, float temp, int top_k) {
+    constexpr int SH = LVL == 0 ? 20 : (LVL == 1 ? 8 : 0), NB = LVL == 2 ? 256 : 4096;
+    __shared__ unsigned hist[NB];
+    __shared__ u64 red[NT / 64];
+    __shared__ int s_pick;
+    __shared__ u64 s_below;
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    u64* ws = wsp + (size_t)b * (WS_FLOATS / 2);
+    const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
+    for (int i = tid; i < NB; i += NT) hist[i] = 0;
+    unsigned prefix = 0, hi_mask = 0;
+    if (LVL > 0) {
+        const u64 cut = (u64)(top_k - 1);
+        u64 below = 0;
+        prefix = (unsigned)pick_bin(ws + WS_C0, 4096, cut, &below, red, &s_pick, &s_below) << 20;
+        hi_mask = 0xffffffffu << 20;
+        if (LVL > 1) {
+            prefix |= (unsigned)pick_bin(ws + WS_C1, 4096, cut, &below, red, &s_pick, &s_below) << 8;
+            hi_mask = 0xffffffffu << 8;
+        }
+    }
+    __syncthreads();
+    for_each_score(r, blk, [&](int i, float s) {
+        if (i >= V) return;
+        const unsigned inv = ~score_key(s);
+        if ((inv & hi_mask) == prefix) atomicAdd(&hist[(inv >> SH) & (NB - 1)], 1u);
+    });
+    __syncthreads();
+    u64* gh = ws + (LVL == 0 ? WS_C0 : (LVL == 1 ? WS_C1 : WS_C2));
+    for (int i = tid; i < NB; i += NT)
+        if (hist[i]) atomicAdd(gh + i, (u64)hist[i]);
+}
+
+// top-k: one block per row resolves the key of the k-th largest score (fewer than k scores: the smallest one)
+__global__ __launch_bounds__(NT) void sample_kth_kernel(u64* __restrict__ wsp, int top_k) {
+    __shared__ u64 red[NT / 64];
+    __shared__ int s_pick;
+    __shared__ u64 s_below;
+    u64* ws = wsp + (size_t)blockIdx.x * (WS_FLOATS / 2);
+    const u64 cut = (u64)(top_k - 1);
+    u64 below = 0;
+    unsigned inv = (unsigned)pick_bin(ws + WS_C0, 4096, cut, &below, red, &s_pick, &s_below) << 20;
+    inv |= (unsigned)pick_bin(ws + WS_C1, 4096, cut, &below, red, &s_pick, &s_below) << 8;
+    inv |= (unsigned)pick_bin(ws + WS_C2, 256, cut, &below, red, &s_pick, &s_below);
+    if (threadIdx.x == 0) ws[WS_KTH] = (u64)(~inv);
+}
+
 // K2..K4 (LVL 0,1,2): mass histogram over 12 / 12 / 7 bits of e = exp(s - max) for the elements that match the bits
 // decided by the earlier levels.  Radix select of the smallest tau with mass{e <= tau} > (1 - top_p) z: the kept set
 // is {e >= tau} (TF keeps the complement of the ascending prefix with cumulative probability <= 1 - top_p).
@@ -243,7 +306,9 @@ __global__ __launch_bounds__(NT) void sample_hist_kernel(const bf16_t* __restric
     }
     __syncthreads();
     u64 zsum = 0;
+    const unsigned kth = (unsigned)ws[WS_KTH];
     for_each_score(r, blk, [&](int, float s) {
+        if (score_key(s) < kth) return;   // removed by top-k
         const float e = expf(s - mx);
         const u64 fx = to_fx(e);
         const unsigned bits = __float_as_uint(e);
@@ -280,9 +345,10 @@ __global__ __launch_bounds__(NT) void sample_mass_kernel(const bf16_t* __restric
         prefix |= (unsigned)pick_bin(ws + WS_H2, 128, cut, &below, red, &s_pick, &s_below);
     }
     u64 mine = 0;
+    const unsigned kth = (unsigned)ws[WS_KTH];
     for_each_score(r, blk, [&](int, float s) {
         const float e = expf(s - mx);
-        if (__float_as_uint(e) >= prefix) mine += to_fx(e);
+        if (score_key(s) >= kth && __float_as_uint(e) >= prefix) mine += to_fx(e);
     });
     mine = block_sum_u64(mine, red);
     if (threadIdx.x == 0) {
@@ -317,11 +383,11 @@ __global__ __launch_bounds__(NT) void sample_draw_kernel(const bf16_t* __restric
     if (!(blk_mass > 0 && blk_before <= target && target < blk_before + blk_mass)) return;  // block-uniform
     const Row r = make_row(logits, seen, b, V, ldl, rep, temp);
     const float mx = row_max(ws);
-    const unsigned prefix = (unsigned)ws[WS_PREFIX];
+    const unsigned prefix = (unsigned)ws[WS_PREFIX], kth = (unsigned)ws[WS_KTH];
     u64 mine = 0;
     for_each_score(r, blk, [&](int, float s) {
         const float e = expf(s - mx);
-        if (__float_as_uint(e) >= prefix) mine += to_fx(e);
+        if (score_key(s) >= kth && __float_as_uint(e) >= prefix) mine += to_fx(e);
     });
     u64 btot;
     const u64 before = blk_before + block_scan_excl_u64(mine, red, &btot);
@@ -332,7 +398,7 @@ __global__ __launch_bounds__(NT) void sample_draw_kernel(const bf16_t* __restric
         for_each_score(r, blk, [&](int i, float s) {
             if (pick >= 0) return;
             const float e = expf(s - mx);
-            if (__float_as_uint(e) >= prefix) {
+            if (score_key(s) >= kth && __float_as_uint(e) >= prefix) {
                 run += to_fx(e);
                 if (run > target) {
                     pick = i;
@@ -354,12 +420,12 @@ __global__ __launch_bounds__(NT) void sample_draw_kernel(const bf16_t* __restric
 
 }  // namespace
 
-extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids,
-                                float* chosen_logprob, const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl,
-                                float rep_penalty, float temperature, float top_p, uint64_t seed, const int* row_id, int step,
-                                int out_stride, float* scratch, hipStream_t stream) {
+extern "C" int o3v_sample_top_k_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids,
+                                      float* chosen_logprob, const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl,
+                                      float rep_penalty, float temperature, int top_k, float top_p, uint64_t seed,
+                                      const int* row_id, int step, int out_stride, float* scratch, hipStream_t stream) {
     if (!logits || !seen || !cur_tok || !finished || !out_ids || !scratch || B < 0 || V <= 0 || step < 0 ||
-        step >= out_stride || !(temperature > 0.f) || !(top_p > 0.f) || (reinterpret_cast<uintptr_t>(scratch) & 7))
+        step >= out_stride || !(temperature > 0.f) || !(top_p > 0.f) || top_k < 0 || (reinterpret_cast<uintptr_t>(scratch) & 7))
         return O3V_ERR_ARG;
     if (B == 0) return O3V_OK;
     const bf16_t* lg = (const bf16_t*)logits;
@@ -367,6 +433,12 @@ extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, in
     u64* ws = (u64*)scratch;
     const dim3 grid(NBLK, B), block(NT);
     O3V_KLAUNCH(sample_max_kernel, grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature);
+    if (top_k > 0 && top_k < V) {  // TF:591: top_k = min(top_k, vocabulary); k == V removes nothing
+        O3V_KLAUNCH((sample_count_kernel<0>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_k);
+        O3V_KLAUNCH((sample_count_kernel<1>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_k);
+        O3V_KLAUNCH((sample_count_kernel<2>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_k);
+        O3V_KLAUNCH(sample_kth_kernel, dim3(B), block, 0, stream, ws, top_k);
+    }
     O3V_KLAUNCH((sample_hist_kernel<0>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
     if (top_p < 1.0f) {
         O3V_KLAUNCH((sample_hist_kernel<1>), grid, block, 0, stream, lg, sn, ws, V, ldl, rep_penalty, temperature, top_p);
@@ -377,4 +449,12 @@ extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, in
                 pad_id, V, ldl, rep_penalty, temperature, seed, row_id, step, out_stride);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_sample_top_p(const void* logits, void* seen, int* cur_tok, int* finished, int* out_ids,
+                                float* chosen_logprob, const int* eos_ids, int n_eos, int pad_id, int B, int V, int ldl,
+                                float rep_penalty, float temperature, float top_p, uint64_t seed, const int* row_id, int step,
+                                int out_stride, float* scratch, hipStream_t stream) {
+    return o3v_sample_top_k_top_p(logits, seen, cur_tok, finished, out_ids, chosen_logprob, eos_ids, n_eos, pad_id, B, V, ldl,
+                                  rep_penalty, temperature, 0, top_p, seed, row_id, step, out_stride, scratch, stream);
 }

@@ -61,10 +61,7 @@ class O3VEngine:
         self.clip_std = (C.c_float * 3)(*CLIP_STD)
         self._vit_plan_cache = {}
         self._prefix = {}   # prefix_key -> {"ids", "k", "v"}: prompt K/V kept for reuse (see generate(prefix_key=...))
-        # side stream for the weight prefetch beside the decode attention (O3V_PREFETCH_MB=0 disables)
         import os
-        self.prefetch_bytes = int(float(os.environ.get("O3V_PREFETCH_MB", "0")) * 1e6)
-        self.side_stream = torch.cuda.Stream(device=self.dev) if self.prefetch_bytes > 0 else None
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
         self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
@@ -195,7 +192,7 @@ class O3VEngine:
     def generate(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
                  max_new_tokens=16, eos_token_ids: Sequence[int] = (), pad_token_id: Optional[int] = None,
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
-                 num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
+                 top_k: int = 0, num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
                  vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 16, return_margins: bool = True,
                  sync_timings: bool = False, prefix_key=None) -> GenerateOutput:
         """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
@@ -347,8 +344,8 @@ class O3VEngine:
                               eos_ids=eos.data_ptr(), k_lo=k_lo.data_ptr(), row_id=rid.data_ptr(),
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
                               sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
-                              ws_bytes=nbytes, side_stream=0 if self.side_stream is None else self.side_stream.cuda_stream,
-                              prefetch_bytes=self.prefetch_bytes, group=group, sync=0 if sync is None else sync.data_ptr())
+                              ws_bytes=nbytes, group=group, sync=0 if sync is None else sync.data_ptr(),
+                              top_k=max(0, int(top_k or 0)))
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
         use_eos = len(eos_token_ids) > 0

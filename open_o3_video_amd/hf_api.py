@@ -26,13 +26,44 @@ MAX_ROWS = 16  # sequences per engine call (O3VEngine.MAX_ROWS)
 
 
 class GenerationConfigLike(SimpleNamespace):
-    """Duck-typed subset of transformers.GenerationConfig (max_new_tokens, do_sample, temperature, top_p,
-    repetition_penalty, num_return_sequences, pad_token_id, eos_token_id)."""
+    """Duck-typed subset of transformers.GenerationConfig (max_new_tokens, do_sample, temperature, top_k, top_p,
+    repetition_penalty, num_return_sequences, pad_token_id, eos_token_id).  A field that is absent or None is "not set by the
+    caller", exactly as in transformers >= 5 where GenerationConfig() leaves everything it was not given at None."""
 
 
-def _get(gc, name, default):
-    v = getattr(gc, name, None) if gc is not None else None
-    return default if v is None else v
+# GenerationConfig._get_default_generation_params() of transformers 5.15 for the fields the path reads
+GLOBAL_GENERATION_DEFAULTS = dict(max_new_tokens=20, do_sample=False, temperature=1.0, top_k=50, top_p=1.0,
+                                  repetition_penalty=1.0, num_return_sequences=1)
+_GEN_FIELDS = tuple(GLOBAL_GENERATION_DEFAULTS) + ("pad_token_id", "eos_token_id", "bos_token_id")
+
+
+def load_generation_config(path: str) -> dict:
+    """<checkpoint>/generation_config.json (what GenerationConfig.from_pretrained reads); {} if the file is absent."""
+    f = os.path.join(path, "generation_config.json")
+    if not os.path.isfile(f):
+        return {}
+    import json
+    with open(f) as fh:
+        d = json.load(fh)
+    return {k: v for k, v in d.items() if k in _GEN_FIELDS and v is not None}
+
+
+def resolve_generation_config(passed, model_gc, kwargs) -> dict:
+    """GenerationMixin._prepare_generation_config (TF:generation/utils.py, 5.15): priority kwargs > the passed
+    generation_config's set fields > model.generation_config (the checkpoint's generation_config.json) > global defaults
+    (top_k 50, repetition_penalty 1.0, ...).  So a trainer config that leaves top_k / eos_token_id / repetition_penalty
+    unset (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313) inherits them from the checkpoint, then from the defaults."""
+    out = {}
+    for k in _GEN_FIELDS:
+        v = kwargs.get(k)
+        if v is None and passed is not None:
+            v = getattr(passed, k, None)
+        if v is None and model_gc is not None:
+            v = getattr(model_gc, k, None)
+        if v is None:
+            v = GLOBAL_GENERATION_DEFAULTS.get(k)
+        out[k] = v
+    return out
 
 
 class Qwen2_5_VLForConditionalGeneration:
@@ -43,9 +74,9 @@ class Qwen2_5_VLForConditionalGeneration:
                                       video_token_id=cfg.video_token_id, eos_token_id=cfg.eos_token_id,
                                       pad_token_id=cfg.pad_token_id, vocab_size=cfg.text.vocab_size)
         self.warnings_issued = {}          # R:grpo_trainer.py:330 touches it
-        self.generation_config = GenerationConfigLike(max_new_tokens=20, do_sample=False, temperature=1.0, top_p=1.0,
-                                                      repetition_penalty=1.0, num_return_sequences=1,
-                                                      pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id)
+        # GenerationConfig.from_model_config: only the special tokens come from config.json; from_pretrained replaces this by
+        # the checkpoint's generation_config.json when there is one
+        self.generation_config = GenerationConfigLike(pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id)
         self.training = False
         self._seed = 0
 
@@ -60,7 +91,11 @@ class Qwen2_5_VLForConditionalGeneration:
             raise ValueError("the MI355X path computes in bf16 (torch_dtype=torch.bfloat16)")
         cfg = O3VConfig.from_pretrained(path)
         w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device)
-        return cls(cfg, O3VEngine(cfg, w))
+        model = cls(cfg, O3VEngine(cfg, w))
+        gc = load_generation_config(path)
+        if gc:
+            model.generation_config = GenerationConfigLike(**gc)
+        return model
 
     @classmethod
     def from_state_dict(cls, cfg_dict: dict, state_dict, device="cuda"):
@@ -91,22 +126,25 @@ class Qwen2_5_VLForConditionalGeneration:
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
                  pixel_values_videos=None, video_grid_thw=None, generation_config=None, **kw):
-        if pixel_values_videos is not None:
-            raise NotImplementedError("native video inputs (pixel_values_videos): the reference feeds frames as images "
-                                      "(R:grpo_trainer.py:540-548); pass pixel_values / image_grid_thw")
-        gc = generation_config or self.generation_config
-        G = int(kw.get("num_return_sequences", _get(gc, "num_return_sequences", 1)))
-        T = int(kw.get("max_new_tokens", _get(gc, "max_new_tokens", 20)))
-        do_sample = bool(kw.get("do_sample", _get(gc, "do_sample", False)))
-        eos = kw.get("eos_token_id", _get(gc, "eos_token_id", self.o3v_config.eos_token_id))
+        if pixel_values is None and pixel_values_videos is not None:
+            pixel_values, image_grid_thw = self._video_as_images(pixel_values_videos, video_grid_thw)
+        r = resolve_generation_config(generation_config, self.generation_config, kw)
+        G, T, do_sample = int(r["num_return_sequences"]), int(r["max_new_tokens"]), bool(r["do_sample"])
+        eos = r["eos_token_id"]
         eos = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])
-        pad = int(kw.get("pad_token_id", _get(gc, "pad_token_id", self.o3v_config.pad_token_id)))
-        common = dict(max_new_tokens=T, eos_token_ids=eos, pad_token_id=pad,
-                      repetition_penalty=float(kw.get("repetition_penalty", _get(gc, "repetition_penalty", 1.0))),
-                      do_sample=do_sample, temperature=float(kw.get("temperature", _get(gc, "temperature", 1.0)) or 1.0),
-                      top_p=float(kw.get("top_p", _get(gc, "top_p", 1.0)) or 1.0), seed=self._seed)
+        pad = r["pad_token_id"]
+        if pad is None:
+            if not eos:
+                raise ValueError("generate needs a pad_token_id (or an eos_token_id to fall back on)")
+            pad = eos[0]          # TF:generation/utils.py _prepare_special_tokens: pad defaults to the first eos id
+        pad = int(pad)
+        top_k = int(r["top_k"] or 0) if do_sample else 0
+        common = dict(max_new_tokens=T, eos_token_ids=eos, pad_token_id=pad, repetition_penalty=float(r["repetition_penalty"]),
+                      do_sample=do_sample, temperature=float(r["temperature"] or 1.0), top_p=float(r["top_p"] or 1.0),
+                      top_k=top_k, seed=self._seed)
         self._seed += 1
         ids = torch.as_tensor(input_ids).cpu().numpy()
+        self._check_no_video_tokens(ids)
         B = ids.shape[0]
         mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
         grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()
@@ -117,7 +155,7 @@ class Qwen2_5_VLForConditionalGeneration:
         step = max(1, MAX_ROWS // G)
         # first global completion index of this call: a rank that decodes rows row0..row0+G-1 of a larger group keys its
         # sampler by those indices, so the group is the same whichever ranks produced its rows (partitioning B)
-        row0 = int(kw.get("row_id_offset", _get(gc, "row_id_offset", 0)))
+        row0 = int(kw.get("row_id_offset", getattr(generation_config, "row_id_offset", 0) or 0))
         for b0 in range(0, B, step):
             b1 = min(B, b0 + step)
             pv, gr = self._cat_pixels(per_prompt_pixels[b0:b1])
@@ -128,6 +166,24 @@ class Qwen2_5_VLForConditionalGeneration:
         L = max(r.shape[1] for r in rows)
         rows = [torch.nn.functional.pad(r, (0, L - r.shape[1]), value=pad) for r in rows]
         return torch.cat(rows, dim=0)
+
+    def _video_as_images(self, pixel_values_videos, video_grid_thw):
+        """The non-multi-image branch of the trainer hands the processor's video tensors over
+        (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:555-564, :604-606).  A video grid [t, h, w] holds t temporal patches of
+        two frames each; its pixel rows are t consecutive blocks of h*w patches, each exactly what an image of grid [1, h, w]
+        would hold, so the rows run through the same engine path as t images -- PROVIDED the prompt marks them with the image
+        placeholder: <|video_pad|> prompts get different rope positions (TF:892-942 advances time per temporal patch with
+        second_per_grid_ts) which this engine does not build."""
+        if video_grid_thw is None:
+            raise ValueError("pixel_values_videos needs video_grid_thw")
+        g = torch.as_tensor(video_grid_thw).cpu().numpy().reshape(-1, 3)
+        grid = np.concatenate([np.tile(np.asarray([[1, h, w]], dtype=np.int64), (int(t), 1)) for t, h, w in g], axis=0)
+        return pixel_values_videos, grid
+
+    def _check_no_video_tokens(self, ids):
+        if (ids == self.o3v_config.video_token_id).any():
+            raise NotImplementedError("prompts with <|video_pad|> placeholders are not supported: the reference feeds frames "
+                                      "as images (R:grpo_trainer.py:540-548); expand the video into <|image_pad|> runs")
 
     def _split_pixels(self, ids, pixel_values, grid):
         """Pixel rows / grid rows belonging to each prompt (placeholders are consumed in order)."""
@@ -163,8 +219,12 @@ class Qwen2_5_VLForConditionalGeneration:
 
     # ---- forward (logits), as _get_per_token_logps calls it
     @torch.no_grad()
-    def __call__(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, **kw):
+    def __call__(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, pixel_values_videos=None,
+                 video_grid_thw=None, **kw):
+        if pixel_values is None and pixel_values_videos is not None:
+            pixel_values, image_grid_thw = self._video_as_images(pixel_values_videos, video_grid_thw)
         ids = torch.as_tensor(input_ids).cpu().numpy()
+        self._check_no_video_tokens(ids)
         B = ids.shape[0]
         mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
         grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()

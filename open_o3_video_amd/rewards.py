@@ -73,6 +73,30 @@ def _temporal_iou(pred: Sequence[float], gt: Sequence[float]) -> float:
 
 
 # ---------------------------------------------------------------------------------------------- ROUGE (free-form)
+ALLOW_APPROX_ROUGE = False   # opt-in: free-form answers scored by the approximate ROUGE below when rouge_score is absent
+_ROUGE_WARNED = False
+
+
+def _require_rouge():
+    """Raises unless rouge_score is importable or the approximate scorer was opted into (then warns once).  Called by
+    ans_acc_reward BEFORE its per-completion try/except, so a missing package is an error, not a silent 0.0 reward."""
+    global _ROUGE_WARNED
+    try:
+        import rouge_score  # type: ignore # noqa: F401
+        return
+    except ImportError:
+        pass
+    if not ALLOW_APPROX_ROUGE:
+        raise ImportError("ans_acc_reward's free-form branch needs the `rouge_score` package (the reference imports it); set "
+                          "open_o3_video_amd.rewards.ALLOW_APPROX_ROUGE = True to use the built-in tokenizer-only ROUGE, whose "
+                          "values differ from rouge_score's (no stemming): parity of this branch is unpinned")
+    if not _ROUGE_WARNED:
+        import warnings
+        warnings.warn("rouge_score is not installed: free-form ans_acc rewards use an approximate ROUGE (no stemming); they "
+                      "differ from the reference's", RuntimeWarning)
+        _ROUGE_WARNED = True
+
+
 def _rouge_avg_f(reference: str, hypothesis: str) -> float:
     """mean F of ROUGE-1/2/L with stemming, via the `rouge_score` package the reference uses (:28-32).  The package
     is not installable offline; without it a plain-token implementation is used -> parity of this ONE branch is
@@ -83,6 +107,7 @@ def _rouge_avg_f(reference: str, hypothesis: str) -> float:
         return (sc["rouge1"].fmeasure + sc["rouge2"].fmeasure + sc["rougeL"].fmeasure) / 3
     except ImportError:
         pass
+    _require_rouge()
     import re
     tok = lambda s: [t for t in re.sub(r"[^a-z0-9]+", " ", s.lower()).split() if t]  # noqa: E731
     r, h = tok(reference), tok(hypothesis)
@@ -122,6 +147,8 @@ def ans_acc_reward(completions, answer, **kwargs):
     task = kwargs["task"][0]
     mode = {T_TEMPORAL_MCQ: "TG_MCQ", T_GENERAL_MCQ: "MCQ", T_VISUAL: "none", T_TEMPORAL: "none"}.get(task, "free-form")
     idx = [0]  # the reference advances its own index only on success (:80): keep that quirk
+    if mode == "free-form":
+        _require_rouge()
 
     def score(i, text):
         out = spans.split_completion(text).answer_trimmed

@@ -114,9 +114,11 @@ class GroupRollout:
         if sharded and self.G % world:
             raise ValueError(f"num_generations={self.G} is not divisible by the {world} ranks of the group")
         G_local = self.G // world if sharded else self.G
+        # exactly the fields the trainer sets (R:…:306-313): top_k, eos_token_id and repetition_penalty stay unset and are
+        # resolved by the model the way HF does (checkpoint generation_config.json, then top_k 50 / penalty 1.0)
         gc = GenerationConfigLike(max_new_tokens=self.T, do_sample=True, top_p=self.top_p, temperature=self.temperature,
-                                  num_return_sequences=G_local, pad_token_id=self.pad, eos_token_id=self.eos,
-                                  repetition_penalty=1.0, row_id_offset=rank * G_local if sharded else 0)
+                                  num_return_sequences=G_local, pad_token_id=self.pad,
+                                  row_id_offset=rank * G_local if sharded else 0)
         pc = self.model.generate(input_ids=ids, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
                                  generation_config=gc)
         S = ids.shape[1]

@@ -86,6 +86,11 @@ class LLM:
                 max_pixels = pc.get("max_pixels", max_pixels)
         if tokenizer is None:
             raise ValueError("a tokenizer is required (encode / decode / convert_tokens_to_ids)")
+        self.generation_eos_ids = []
+        if model is not None and os.path.isdir(model):
+            from .hf_api import load_generation_config
+            ge = load_generation_config(model).get("eos_token_id")
+            self.generation_eos_ids = [] if ge is None else ([int(e) for e in ge] if isinstance(ge, (list, tuple)) else [int(ge)])
         self.engine, self.tokenizer = engine, tokenizer
         self.max_num_seqs = int(max_num_seqs)   # requests of one generate() call decoded together (<= O3VEngine.MAX_ROWS)
         self.cfg = engine.cfg
@@ -108,9 +113,12 @@ class LLM:
     def _frames(self, mm) -> Optional[torch.Tensor]:
         if not mm:
             return None
+        if mm.get("video", None) is not None:
+            # R:eval/models/model_vllm.py:92-126 sends frames under "image" (one <|image_pad|> per frame); a native "video"
+            # entry needs <|video_pad|> expansion and per-temporal-patch rope positions, which this engine does not build
+            raise NotImplementedError("multi_modal_data['video'] is not supported: pass the frames under 'image' with one "
+                                      "<|image_pad|> per frame, as eval/inference_example.py does")
         data = mm.get("image", None)
-        if data is None:
-            data = mm.get("video", None)
         if data is None:
             return None
         if isinstance(data, (list, tuple)):
@@ -142,12 +150,15 @@ class LLM:
         return data
 
     def _visual_tokens(self, frames: torch.Tensor) -> torch.Tensor:
-        """ViT + merger output for `frames`, cached by content (shape, dtype, 2 checksums computed on the device)."""
-        fr = frames.to(self.engine.dev)
-        flat = fr.reshape(-1).to(torch.float64)
-        n = flat.numel()
-        key = (tuple(fr.shape), str(fr.dtype), float(flat.sum().item()),
-               float((flat * torch.arange(1, n + 1, device=fr.device, dtype=torch.float64).remainder_(8191.0)).sum().item()))
+        """ViT + merger output for `frames`, cached by content: (shape, dtype, 128-bit hash of the bytes computed on the device
+        by o3v_content_hash128 -- one pass over the frames, one 16-byte read-back)."""
+        import ctypes as C
+        from . import _lib
+        fr = frames.to(self.engine.dev).contiguous()
+        h = torch.zeros(2, dtype=torch.int64, device=fr.device)
+        _lib.call("o3v_content_hash128", C.c_void_p(fr.data_ptr()), fr.numel() * fr.element_size(), C.c_void_p(h.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        key = (tuple(fr.shape), str(fr.dtype)) + tuple(int(v) for v in h.tolist())
         hit = self._vis_cache.get(key)
         if hit is not None:
             self.vis_cache_hits += 1
@@ -173,8 +184,10 @@ class LLM:
         if isinstance(inputs, dict):
             inputs = [inputs]
         greedy = sp.temperature == 0.0
+        # vLLM stops on the request's stop ids, the model's eos id and every eos id of the checkpoint's generation_config.json
         stop = list(sp.stop_token_ids) if sp.stop_token_ids else []
-        eos = stop + ([self.cfg.eos_token_id] if self.cfg.eos_token_id is not None else [])
+        eos = stop + [e for e in ([self.cfg.eos_token_id] + list(self.generation_eos_ids)) if e is not None and e not in stop]
+        eos = list(dict.fromkeys(int(e) for e in eos))
         common = dict(max_new_tokens=sp.max_tokens, eos_token_ids=eos, pad_token_id=self.cfg.pad_token_id,
                       repetition_penalty=sp.repetition_penalty, do_sample=not greedy,
                       temperature=1.0 if greedy else sp.temperature, top_p=1.0 if greedy else sp.top_p, return_margins=False)

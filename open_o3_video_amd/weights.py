@@ -147,8 +147,8 @@ class DeviceWeights:
         else:
             try:
                 keep["l.head"] = g("lm_head.weight").contiguous()
-            except KeyError:
-                keep["l.head"] = keep["l.embed"]
+            except KeyError as e:   # an incomplete shard / index or a renamed key must not silently turn into a tied head
+                raise KeyError("lm_head.weight is missing from the checkpoint although tie_word_embeddings is false") from e
         head_p = 0
         if batched_decode and keep["l.head"].shape[0] % 16 == 0 and keep["l.head"].shape[1] % 32 == 0:
             keep["l.headp"] = pack_mfma_fragments(keep["l.head"])

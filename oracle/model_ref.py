@@ -240,6 +240,13 @@ def temperature_warp(scores, t):
     return scores / t
 
 
+def top_k_warp(scores, top_k, filter_value=-float("inf")):
+    # TF:generation/logits_process.py:590-594 (TopKLogitsWarper): everything below the k-th largest score goes; ties stay
+    top_k = min(int(top_k), scores.shape[-1])
+    kth = torch.topk(scores, top_k)[0][..., -1, None]
+    return scores.masked_fill(scores < kth, filter_value)
+
+
 def top_p_warp(scores, top_p, min_keep=1, filter_value=-float("inf")):
     # TF:generation/logits_process.py:527-539
     sl, si = torch.sort(scores, descending=False)
@@ -254,7 +261,7 @@ def top_p_warp(scores, top_p, min_keep=1, filter_value=-float("inf")):
 def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens,
              dtype=torch.float32, eos_token_ids=(), pad_token_id=0, rep_penalty=1.0,
              do_sample=False, temperature=1.0, top_p=1.0, generator=None, taps=None,
-             return_logits=False):
+             return_logits=False, top_k=0):
     """Greedy / sampled decode, TF:generation/utils.py:2783-2942 (_sample) over
     TF:modeling_qwen2_5_vl.py:1185-1253,1308-1402.  Returns ids [B, S+T] (and the fp32
     last-token logits per step when return_logits)."""
@@ -297,6 +304,8 @@ def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, ma
         if do_sample:
             if temperature != 1.0:
                 scores = temperature_warp(scores, temperature)
+            if top_k:
+                scores = top_k_warp(scores, top_k)
             if top_p < 1.0:
                 scores = top_p_warp(scores, top_p)
             probs = F.softmax(scores, dim=-1)

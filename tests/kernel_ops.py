@@ -1,13 +1,13 @@
-"""Thin torch-tensor wrappers over the per-op entry points of the C ABI (used by the parity tests; the engine
-calls the model-level entry points instead).  Every wrapper launches on the current torch stream."""
+"""Test helpers: thin torch-tensor wrappers over the per-op entry points of the C ABI (the engine calls the model-level
+entry points instead).  Every wrapper launches on the current torch stream.  Used by tests/ and tools/ only."""
 from __future__ import annotations
 
 import ctypes as C
 
 import torch
 
-from . import _lib
-from ._lib import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU  # noqa: F401
+from open_o3_video_amd import _lib
+from open_o3_video_amd._lib import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU  # noqa: F401
 
 
 def _p(t):
@@ -24,15 +24,18 @@ def rmsnorm(x, w, eps):
     return out
 
 
-def gemm(a, w, bias=None, res=None, epi=EPI_NONE, force=None):
-    """out = epi(a @ w.T + bias).  force in {None,'gemm','gemv'}."""
+def gemm(a, w, bias=None, res=None, epi=EPI_NONE, force=None, tile=0):
+    """out = epi(a @ w.T + bias).  force in {None,'gemm','gemv'}; tile 0 / 128 / 256 picks the MFMA GEMM kernel."""
     M, K = a.shape
     N = w.shape[0]
     No = N // 2 if epi == EPI_SWIGLU else N
     out = torch.empty((M, No), dtype=torch.bfloat16, device=a.device)
-    fn = "o3v_gemv_bf16" if (force == "gemv" or (force is None and M <= 8)) else "o3v_gemm_bf16"
-    _lib.call(fn, _p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
-              0 if res is None else res.stride(0), epi, _s())
+    ldr = 0 if res is None else res.stride(0)
+    if force == "gemv" or (force is None and M <= 8):
+        _lib.call("o3v_gemv_bf16", _p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr, epi, _s())
+    else:
+        _lib.call("o3v_gemm_bf16_tile", _p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
+                  epi, tile, _s())
     return out
 
 

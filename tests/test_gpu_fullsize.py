@@ -149,10 +149,10 @@ def test_fullsize_reuse_paths(eng7b):
     assert d.max().item() < 1.0 and d.mean().item() < 0.3
     # P8
     try:
-        _lib.call("o3v_gemm_set_tile", 128)
+        eng.w.vit.gemm_tile = eng.w.llm.gemm_tile = 128      # the descriptors carry the tile choice (0 = per shape)
         l128 = eng.forward_logits(np.asarray([ids]), None, frames=frames)[0, -1]
-        _lib.call("o3v_gemm_set_tile", 0)
+        eng.w.vit.gemm_tile = eng.w.llm.gemm_tile = 0
         lauto = eng.forward_logits(np.asarray([ids]), None, frames=frames)[0, -1]
     finally:
-        _lib.call("o3v_gemm_set_tile", 0)
+        eng.w.vit.gemm_tile = eng.w.llm.gemm_tile = 0
     assert torch.equal(l128, lauto)

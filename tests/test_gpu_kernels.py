@@ -42,7 +42,7 @@ def close_bf16(got, ref, ulps=2, atol=1e-3, frac=0.999):
 
 
 def test_rmsnorm(dev):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     from oracle import model_ref
     g = torch.Generator().manual_seed(0)
     for rows, cols in [(1, 64), (5, 128), (37, 1280), (130, 3584), (3, 5120)]:
@@ -54,7 +54,7 @@ def test_rmsnorm(dev):
 
 
 def _epi_ref(acc, bias, res, epi):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     v = acc + (bias.float() if bias is not None else 0)
     if epi == ops.EPI_NONE:
         return rb(v)
@@ -68,7 +68,7 @@ def _epi_ref(acc, bias, res, epi):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 192, 320), (1, 64, 64), (77, 1280, 1216),
                                     (515, 3456, 1280), (300, 4608, 3584), (130, 128, 1152)])
 def test_gemm_epilogues(dev, M, N, K):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(M * 131 + N)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
@@ -94,7 +94,7 @@ def test_gemm_epilogues(dev, M, N, K):
 def test_gemm_splitk(dev, M, N, K, splits):
     """Split-K form used for a prompt suffix behind a cached prefix (9..128 rows): same epilogues, same tolerance, and
     bit-identical from run to run (the partials are reduced in split order, no atomics)."""
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
@@ -113,7 +113,8 @@ def test_gemm_splitk(dev, M, N, K, splits):
 def test_gemm_256_tile_kernel(dev, M, N, K):
     """The 8-wave 256x256 kernel (forced here; the launcher picks it for the big prefill shapes): every epilogue, ragged M
     and N edges, against the fp32 reference and bit-identical to the 128-tile kernel (same k order per output element)."""
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     from open_o3_video_amd.weights import pack_gate_up
     g = torch.Generator().manual_seed(M + N)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
@@ -122,32 +123,25 @@ def test_gemm_256_tile_kernel(dev, M, N, K):
     res = torch.randn(M, N, generator=g).to(BF).to(dev)
     acc = a.float() @ w.float().t()
     cases = [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, bias, res), (ops.EPI_GELU, None, None)]
-    try:
-        outs = {}
-        for tile in (256, 128):
-            _lib.call("o3v_gemm_set_tile", tile)
-            outs[tile] = [ops.gemm(a, w, b, r, epi, force="gemm") for epi, b, r in cases]
-        for o256, o128, (epi, b, r) in zip(outs[256], outs[128], cases):
-            close_bf16(o256, _epi_ref(acc, b, r, epi))
-            assert torch.equal(o256, o128)
-        if N % 32 == 0:
-            I = N // 2
-            wg, wu = w[:I].contiguous(), w[I:].contiguous()
-            packed = pack_gate_up(wg, wu, I)
-            sw = []
-            for tile in (256, 128):
-                _lib.call("o3v_gemm_set_tile", tile)
-                sw.append(ops.gemm(a, packed, None, None, ops.EPI_SWIGLU, force="gemm"))
-            assert torch.equal(sw[0], sw[1])
-            gv = rb(a.float() @ wg.float().t())
-            uv = rb(a.float() @ wu.float().t())
-            close_bf16(sw[0], rb(torch.nn.functional.silu(gv)) * uv)
-    finally:
-        _lib.call("o3v_gemm_set_tile", 0)
+    outs = {}
+    for tile in (256, 128):
+        outs[tile] = [ops.gemm(a, w, b, r, epi, force="gemm", tile=tile) for epi, b, r in cases]
+    for o256, o128, (epi, b, r) in zip(outs[256], outs[128], cases):
+        close_bf16(o256, _epi_ref(acc, b, r, epi))
+        assert torch.equal(o256, o128)
+    if N % 32 == 0:
+        I = N // 2
+        wg, wu = w[:I].contiguous(), w[I:].contiguous()
+        packed = pack_gate_up(wg, wu, I)
+        sw = [ops.gemm(a, packed, None, None, ops.EPI_SWIGLU, force="gemm", tile=tile) for tile in (256, 128)]
+        assert torch.equal(sw[0], sw[1])
+        gv = rb(a.float() @ wg.float().t())
+        uv = rb(a.float() @ wu.float().t())
+        close_bf16(sw[0], rb(torch.nn.functional.silu(gv)) * uv)
 
 
 def _swiglu_case(dev, M, I, K, ipad, seed):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     from open_o3_video_amd.weights import pack_gate_up
     g = torch.Generator().manual_seed(seed)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
@@ -163,7 +157,7 @@ def _swiglu_case(dev, M, I, K, ipad, seed):
 
 @pytest.mark.parametrize("M,I,K", [(130, 428, 320), (64, 96, 64), (257, 1152, 896), (5, 256, 128), (1, 1152, 896), (8, 428, 320)])
 def test_swiglu_gemm_and_gemv(dev, M, I, K):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     ipad = (I + 63) // 64 * 64
     a, w, b, ref = _swiglu_case(dev, M, I, K, ipad, M + I)
     for force in (["gemm", "gemv"] if M <= 8 else ["gemm"]):
@@ -176,7 +170,8 @@ def test_swiglu_gemm_and_gemv(dev, M, I, K):
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 12, 16])
 @pytest.mark.parametrize("N,K", [(64, 128), (4608, 3584), (3584, 18944), (1000, 896), (8192, 1280)])
 def test_gemv(dev, M, N, K):
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     g = torch.Generator().manual_seed(M * 7 + N)
     if M > 8 and N % 16:
         # 9..16 rows exist only on the matrix-core path, which needs whole 16-row weight blocks: refused, not mis-computed
@@ -199,7 +194,8 @@ def test_gemv(dev, M, N, K):
 def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
     """RMSNorm fused into the decode projections must equal rmsnorm kernel -> gemv (same rounding points)."""
     import ctypes as C
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     from oracle import model_ref
     g = torch.Generator().manual_seed(M + N)
     x = (torch.randn(M, K, generator=g) * 2).to(BF)
@@ -222,7 +218,8 @@ def test_gemv_fused_rmsnorm(dev, M, N, K, epi_name):
 def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
     """Fully fused decode q/k/v projection == rmsnorm -> gemv(+bias) -> qkv_rope_cache (bit-identical outputs)."""
     import ctypes as C
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     g = torch.Generator().manual_seed(M + Hq)
     N, Tmax, Tnew, step, slot = (Hq + 2 * Hkv) * D, 40, 6, 4, 33
     x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
@@ -268,7 +265,8 @@ def test_gemv_fused_norm_qkv_rope_cache(dev, M, Hq, Hkv, D, K):
 def test_linear_decode_packed_weights(dev, M, N, K, epi_name, norm):
     """o3v_linear_decode with the MFMA-fragment-major weight copy == the row-major path (all epilogues, fused norm)."""
     import ctypes as C
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     from open_o3_video_amd.weights import pack_mfma_fragments
     g = torch.Generator().manual_seed(M * 3 + N)
     x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
@@ -300,7 +298,8 @@ def test_linear_decode_packed_weights(dev, M, N, K, epi_name, norm):
 
 
 def test_gemm_rejects_bad_shapes(dev):
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     a = torch.zeros(4, 100, dtype=BF, device=dev)
     w = torch.zeros(8, 100, dtype=BF, device=dev)
     with pytest.raises(_lib.O3VError):
@@ -310,7 +309,7 @@ def test_gemm_rejects_bad_shapes(dev):
 
 
 def test_vit_rope(dev):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     from oracle.model_ref import rotate_half
     g = torch.Generator().manual_seed(3)
     for P, H, D in [(48, 2, 32), (100, 4, 80), (33, 3, 64)]:
@@ -385,7 +384,8 @@ def _attn_ref(q, k, v, scale, mask=None):
                                       (2, 128, [200, 33])])
 def test_attn_varlen_noncausal(dev, H, D, lens):
     """ViT attention over ragged segments, q/k/v read in place from the fused qkv buffer."""
-    from open_o3_video_amd import ops, indexing
+    import kernel_ops as ops
+    from open_o3_video_amd import indexing
     g = torch.Generator().manual_seed(sum(lens) + D)
     P = sum(lens)
     qkv = torch.randn(P, 3, H, D, generator=g).to(BF)
@@ -406,7 +406,8 @@ def test_attn_varlen_noncausal(dev, H, D, lens):
                                              (4, 4, 64, 129, [64, 0, 127])])
 @pytest.mark.parametrize("tile", [64, 128])
 def test_attn_causal_gqa_prefill(dev, Hq, Hkv, D, S, pads, tile):
-    from open_o3_video_amd import ops, indexing
+    import kernel_ops as ops
+    from open_o3_video_amd import indexing
     B, Tmax = len(pads), S + 9
     g = torch.Generator().manual_seed(S + D)
     q = torch.randn(B, S, Hq, D, generator=g).to(BF)
@@ -430,7 +431,8 @@ def test_attn_causal_gqa_prefill(dev, Hq, Hkv, D, S, pads, tile):
 
 def test_attn_online_softmax_rescale_branch(dev):
     """Force the running max to jump late (spiked key in the last tile) -- the rescale path must be exact."""
-    from open_o3_video_amd import ops, indexing
+    import kernel_ops as ops
+    from open_o3_video_amd import indexing
     H, D, L = 1, 128, 256
     g = torch.Generator().manual_seed(11)
     q = torch.randn(L, 1, D, generator=g).to(BF)
@@ -452,7 +454,7 @@ def test_attn_online_softmax_rescale_branch(dev):
                                                          (1, 28, 4, 128, 5001, [17], 37), (4, 7, 1, 128, 1, [0] * 4, 2),
                                                          (2, 8, 1, 128, 130, [129, 0], 1)])
 def test_attn_decode(dev, B, Hq, Hkv, D, ctx, pads, nsplit):
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     Tmax = ctx + 11
     g = torch.Generator().manual_seed(ctx)
     q = torch.randn(B, Hq, D, generator=g).to(BF)
@@ -476,7 +478,7 @@ def test_attn_decode(dev, B, Hq, Hkv, D, ctx, pads, nsplit):
 def test_attn_decode_group(dev, B, G, Hq, Hkv, P, own, pad, nsp):
     """Shared-prefix group decode attention: rows of a group read the prefix K/V of the group's FIRST row only (the other
     rows' prefix slots are poisoned here), their own keys from their own row; checked against fp32 softmax attention."""
-    from open_o3_video_amd import ops
+    import kernel_ops as ops
     D = 128
     ctx = P + own
     Tmax = ctx + 5
@@ -533,7 +535,8 @@ def test_patchify_matches_hf_processor(dev, golden_dir):
 
 def test_gather_and_embed(dev):
     import ctypes as C
-    from open_o3_video_amd import ops, _lib
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
     g = torch.Generator().manual_seed(2)
     src = torch.randn(50, 256, generator=g).to(BF).to(dev)
     idx = torch.randperm(50, generator=g).to(torch.int32).to(dev)
@@ -766,3 +769,63 @@ def test_decode_attn_block_fused_equals_three_launches(dev, Hq, Hkv, H, ctx, Tma
         assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
 
+
+
+@pytest.mark.parametrize("V,top_k,top_p,temp,rep", [(152064, 50, 0.95, 1.0, 1.0), (152064, 1, 1.0, 1.0, 1.0), (152064, 7, 0.9, 0.8, 1.1),
+                                                     (152064, 200000, 0.95, 1.0, 1.0), (997, 20, 0.5, 1.0, 1.0), (997, 3, 1.0, 1.3, 1.0)])
+def test_sample_top_k_top_p(dev, V, top_k, top_p, temp, rep):
+    """o3v_sample_top_k_top_p: every draw lies in the set TF keeps (penalty -> temperature -> TopKLogitsWarper ->
+    TopPLogitsWarper, restated by the oracle and pinned by golden G8b), bf16 ties at the k-th value included (the plateau
+    keeps MORE than k tokens, as TF does; a tie group at the top-p boundary is kept whole); top_k = 1 is greedy; k >= vocabulary removes nothing; the frequencies over many draws
+    follow the renormalised probabilities; the reported log-prob is the softmax over what top-k kept (before top-p)."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from oracle import model_ref
+    B, N = 4, 64 if V > 1000 else 400
+    g = torch.Generator().manual_seed(13 + top_k % 97)
+    base = torch.randn(V, generator=g) * 2.5
+    hot = torch.randint(0, V, (30,), generator=g)
+    base[hot] += 8.0
+    base[hot[10:18]] = float(base[hot[10]])   # a plateau among the largest scores: ties around the k-th place
+    logits = base.to(BF)[None].repeat(B, 1).contiguous()
+    seen0 = torch.zeros(B, V, dtype=torch.uint8)
+    seen0[:, torch.randint(0, V, (200,), generator=g)] = 1
+    sc = logits[:1].float().clone()
+    if rep != 1.0:
+        m = seen0[:1].bool()
+        sc = torch.where(m, torch.where(sc < 0, sc * rep, sc / rep), sc)
+    sc = model_ref.temperature_warp(sc, temp)
+    filt = model_ref.top_k_warp(sc, top_k)
+    if top_p < 1.0:
+        filt = model_ref.top_p_warp(filt, top_p)
+    kept_tf = torch.isfinite(filt[0])
+    # Scores tied with the smallest score TF keeps: TF's ascending sort puts some of them inside the removed prefix and some
+    # outside, by the (unspecified) order of equal elements; the kernel keeps the whole tie group.  No tie: identical sets.
+    topk_only = model_ref.top_k_warp(sc, top_k)[0]
+    kept = topk_only >= filt[0][kept_tf].min()
+    assert (kept | ~kept_tf).all() and (topk_only[kept & ~kept_tf] == filt[0][kept_tf].min()).all()
+    probs = torch.softmax(topk_only.masked_fill(~kept, float("-inf")), dim=-1)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ld = logits.to(dev)
+    out = torch.zeros(B, N, dtype=torch.int32, device=dev)
+    lp = torch.zeros(B, N, device=dev)
+    cur = torch.zeros(B, dtype=torch.int32, device=dev)
+    fin = torch.zeros(B, dtype=torch.int32, device=dev)
+    eos = torch.tensor([V + 1], dtype=torch.int32, device=dev)
+    scratch = torch.empty(B, _lib.SAMPLE_SCRATCH_FLOATS, device=dev)
+    rid = torch.arange(B, dtype=torch.int32, device=dev)
+    for step in range(N):
+        seen = seen0.clone().to(dev)       # the sampler marks what it draws: keep the penalty set fixed for the comparison
+        _lib.call("o3v_sample_top_k_top_p", P(ld), P(seen), P(cur), P(fin), P(out), P(lp), P(eos), 1, 0, B, V, V, rep, temp, top_k,
+                  top_p, 99, P(rid), step, N, P(scratch), st)
+    o = out.cpu().long()
+    assert kept[o.view(-1)].all(), f"sampled outside the top-k/top-p set ({int(kept.sum())} kept, TF {int(kept_tf.sum())})"
+    if top_k == 1:
+        assert (o == int(sc[0].argmax())).all()
+    freq = torch.bincount(o.view(-1), minlength=V).float() / o.numel()
+    tol = 0.12 if V > 1000 else 0.04
+    assert (freq - probs).abs().max().item() < tol
+    ref_lp = torch.log_softmax(model_ref.top_k_warp(sc, top_k)[0], dim=-1)[o.view(-1)].view(B, N)   # softmax over what top-k kept
+    assert (lp.cpu() - ref_lp).abs().max().item() < 2e-3
+    assert len({tuple(r.tolist()) for r in o}) > 1 or int(kept.sum()) == 1

@@ -118,7 +118,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/o3v.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.load().o3v_abi_version() == 2
+    assert _lib.load().o3v_abi_version() == 3
 
 
 def test_c_abi_argument_errors_without_gpu():
@@ -143,3 +143,30 @@ def test_engine_refuses_to_run_without_gpu():
     from open_o3_video_amd.engine import O3VEngine
     with pytest.raises(Exception):
         O3VEngine(O3VConfig.from_dict(fm.tiny_config()), None)
+
+
+def test_generation_config_resolution_matches_hf(golden_dir, tmp_path):
+    """hf_api.resolve_generation_config == GenerationMixin._prepare_generation_config (transformers 5.15, golden G8b) for the
+    trainer's GenerationConfig (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313: top_k / eos / penalty unset) against
+    three checkpoint generation configs, with and without generate() kwargs; and generation_config.json is what is loaded."""
+    import json
+    from open_o3_video_amd.hf_api import GenerationConfigLike, load_generation_config, resolve_generation_config
+    g = np.load(os.path.join(golden_dir, "g8b_top_k.npz"))
+    cases = json.loads(bytes(g["gen_config_cases"]).decode())
+    passed = GenerationConfigLike(**cases["trainer"])
+    for name, mg in cases["models"].items():
+        d = tmp_path / name
+        d.mkdir()
+        if mg:
+            (d / "generation_config.json").write_text(json.dumps(dict(mg, transformers_version="4.37.0")))
+        loaded = load_generation_config(str(d))
+        assert loaded == mg
+        model_gc = GenerationConfigLike(**loaded)
+        for suffix, kw in (("", {}), ("+kwargs", {"top_k": 7, "eos_token_id": 3})):
+            want = cases["resolved"][name + suffix]
+            got = resolve_generation_config(passed, model_gc, kw)
+            for k, v in want.items():
+                assert got[k] == v, (name + suffix, k, got[k], v)
+    # the unset trainer fields fall back to HF's global defaults when the checkpoint says nothing
+    r = resolve_generation_config(passed, GenerationConfigLike(), {})
+    assert r["top_k"] == 50 and r["repetition_penalty"] == 1.0 and r["eos_token_id"] is None

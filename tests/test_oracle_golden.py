@@ -109,6 +109,17 @@ def test_logits_processors(golden_dir):
         assert np.array_equal(model_ref.top_p_warp(s.clone(), p).numpy(), g[f"top_p_{p}"])
 
 
+def test_top_k_processor(golden_dir):
+    """TopKLogitsWarper (incl. ties at the k-th value, k larger than the vocabulary) and the rollout's whole chain."""
+    g = np.load(os.path.join(golden_dir, "g8b_top_k.npz"))
+    s, t = torch.from_numpy(g["scores"]), torch.from_numpy(g["tied"])
+    for k in (1, 50, 2000):
+        assert np.array_equal(model_ref.top_k_warp(s.clone(), k).numpy(), g[f"top_k_{k}"])
+        assert np.array_equal(model_ref.top_k_warp(t.clone(), k).numpy(), g[f"tied_top_k_{k}"])
+    chain = model_ref.top_p_warp(model_ref.top_k_warp(model_ref.temperature_warp(s.clone(), 0.8), 50), 0.95)
+    assert np.array_equal(chain.numpy(), g["chain_t0p8_k50_p0p95"])
+
+
 CASES = [("g6_tiny.npz", fm.tiny_config, 0, 16), ("g6_tiny_b.npz", fm.tiny_config, 1, 12),
          ("g7_medium.npz", fm.medium_config, 2, 16)]
 

@@ -31,19 +31,18 @@ for name, M, N, K, epi, hb in shapes:
     res = torch.zeros(M, No, dtype=torch.bfloat16, device=dev) if epi == 1 else None
     out = torch.empty(M, No, dtype=torch.bfloat16, device=dev)
 
-    def run():
+    def run(tile=0):
         for i in range(nrep):
-            _lib.call("o3v_gemm_bf16", P(a[i]), P(w[i]), P(bias), P(res), P(out), M, N, K, K, K, No, No, epi, st)
+            _lib.call("o3v_gemm_bf16_tile", P(a[i]), P(w[i]), P(bias), P(res), P(out), M, N, K, K, K, No, No, epi, tile, st)
     fl = 2.0 * M * N * K
     line = f"{name:22s} M={M:6d} N={N:6d} K={K:6d} "
     for tile in (128, 256, 0):   # forced 128-tile kernel, forced 256-tile kernel, the launcher's own choice
-        _lib.call("o3v_gemm_set_tile", tile)
-        run()
+        run(tile)
         torch.cuda.synchronize()
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run(); e1.record(); torch.cuda.synchronize()
+            e0.record(); run(tile); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / nrep)
         t = sorted(ts)[2]
         line += f" | {'auto' if tile == 0 else tile}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TFLOP/s"

@@ -31,9 +31,7 @@ while time.time() - t0 < budget:
     epi, b, r = [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, None, res), (ops.EPI_GELU, bias, None)][ri(0, 2)]
     outs = []
     for tile in (0, 128, 256):
-        _lib.call("o3v_gemm_set_tile", tile)
-        outs.append(ops.gemm(a, w, b, r, epi, force="gemm"))
-    _lib.call("o3v_gemm_set_tile", 0)
+        outs.append(ops.gemm(a, w, b, r, epi, force="gemm", tile=tile))
     close_bf16(outs[0], _epi_ref(acc, b, r, epi))
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[1]), (M, N, K)
     if M <= 128:

@@ -308,6 +308,46 @@ def g8_logits_processors():
     print("G8 written")
 
 
+def g8b_top_k():
+    """TopKLogitsWarper alone and the chain the rollout runs (temperature -> top-k -> top-p), on scores with bf16-style
+    ties (the k-th value is shared by several tokens) and without, plus the resolved generation configs of
+    GenerationMixin._prepare_generation_config for the trainer's GenerationConfig against three checkpoint configs."""
+    from transformers import GenerationConfig
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from transformers.generation.utils import GenerationMixin
+    g = torch.Generator().manual_seed(89)
+    scores = torch.randn(4, 997, generator=g) * 3
+    tied = (torch.randn(4, 997, generator=g) * 3).to(torch.bfloat16).float()      # many equal values
+    tied[0, :300] = tied[0, 5]                                                     # a plateau that holds the k-th place
+    ids = torch.zeros(4, 1, dtype=torch.long)
+    res = {"scores": scores.numpy(), "tied": tied.numpy()}
+    for k in (1, 50, 2000):
+        res[f"top_k_{k}"] = TopKLogitsWarper(k)(ids, scores.clone()).numpy()
+        res[f"tied_top_k_{k}"] = TopKLogitsWarper(k)(ids, tied.clone()).numpy()
+    chain = TopPLogitsWarper(0.95)(ids, TopKLogitsWarper(50)(ids, TemperatureLogitsWarper(0.8)(ids, scores.clone())))
+    res["chain_t0p8_k50_p0p95"] = chain.numpy()
+    # generation-config resolution
+    trainer = dict(max_new_tokens=768, do_sample=True, top_p=0.95, temperature=1, num_return_sequences=4, pad_token_id=151643)
+    fields = ("max_new_tokens", "do_sample", "temperature", "top_k", "top_p", "repetition_penalty", "num_return_sequences",
+              "pad_token_id", "eos_token_id")
+    models = {"none": {}, "qwen_like": dict(do_sample=True, eos_token_id=[151645, 151643], pad_token_id=151643,
+                                            repetition_penalty=1.05, temperature=0.1, top_k=1, top_p=0.001),
+              "eos_only": dict(eos_token_id=151645)}
+    import json
+    resolved = {}
+    for name, mg in models.items():
+        fake = type("M", (), {})()
+        fake.generation_config = GenerationConfig(**mg)
+        fake.config = None
+        gc, _ = GenerationMixin._prepare_generation_config(fake, GenerationConfig(**trainer))
+        resolved[name] = {k: getattr(gc, k) for k in fields}
+        gc2, _ = GenerationMixin._prepare_generation_config(fake, GenerationConfig(**trainer), top_k=7, eos_token_id=3)
+        resolved[name + "+kwargs"] = {k: getattr(gc2, k) for k in fields}
+    res["gen_config_cases"] = np.frombuffer(json.dumps({"trainer": trainer, "models": models, "resolved": resolved}).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "g8b_top_k.npz"), **res)
+    print("G8b written", json.dumps(resolved)[:400])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g8"]
     if "g1" in which:
@@ -322,6 +362,8 @@ if __name__ == "__main__":
         g6_g7()
     if "g8" in which:
         g8_logits_processors()
+    if "g8b" in which:
+        g8b_top_k()
 
 
 # ------------------------------------------------------------------------------------------------ G9 rewards / spans

@@ -20,9 +20,7 @@ out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr())
 for tile in (256, 128):
-    _lib.call("o3v_gemm_set_tile", tile)
     for rep in range(4):
-        _lib.call("o3v_gemm_bf16", P(a), P(w), None, None, P(out), M, N, K, K, K, N // 2, 0, 3, st)
+        _lib.call("o3v_gemm_bf16_tile", P(a), P(w), None, None, P(out), M, N, K, K, K, N // 2, 0, 3, tile, st)
 torch.cuda.synchronize()
-_lib.call("o3v_gemm_set_tile", 0)
 print("done: 4 launches per tile size,", 2.0 * M * N * K / 1e12, "TFLOP each")
