@@ -57,6 +57,43 @@ def medium_config():
     }
 
 
+def full7b_config():
+    """Qwen2.5-VL-7B at TRUE depth and width (32 ViT blocks of 1280 / 3420, 28 LLM layers of 3584 / 18944, GQA 28:4,
+    mrope [16,24,24]) with a small vocabulary (4096) so that the seeded weights (6.5 G parameters) and
+    the HF fp32 run fit the build container.  Golden G10 pins the engine at this depth."""
+    return {
+        "model_type": "qwen2_5_vl",
+        **SPECIAL,
+        "image_token_id": 4000, "video_token_id": 4001, "vision_start_token_id": 3998,
+        "vision_end_token_id": 3999, "eos_token_id": 4010, "pad_token_id": 4011, "bos_token_id": 4009,
+        "tie_word_embeddings": False,
+        "vision_config": {
+            "depth": 32, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420,
+            "out_hidden_size": 3584, "patch_size": 14, "temporal_patch_size": 2,
+            "spatial_merge_size": 2, "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31],
+            "in_channels": 3, "hidden_act": "silu", "tokens_per_second": 2,
+        },
+        "text_config": {
+            "hidden_size": 3584, "num_hidden_layers": 28, "num_attention_heads": 28,
+            "num_key_value_heads": 4, "intermediate_size": 18944, "vocab_size": 4096,
+            "rms_norm_eps": 1e-6, "rope_theta": 1000000.0, "mrope_section": [16, 24, 24],
+            "hidden_act": "silu", "max_position_embeddings": 32768, "tie_word_embeddings": False,
+        },
+    }
+
+
+def tied3b_config():
+    """Qwen2.5-VL-3B's distinguishing features at fixture size: tied word embeddings (lm_head = embed_tokens), GQA 8:1
+    (16 query / 2 kv heads of 128), 36-layer structure cut to 3 layers.  Golden G11."""
+    c = medium_config()
+    c["tie_word_embeddings"] = True
+    c["fixture_embed_scale"] = 0.06      # the embedding doubles as the head: keeps the logits O(1..10)
+    c["text_config"] = dict(c["text_config"], hidden_size=2048, num_attention_heads=16, num_key_value_heads=2,
+                            intermediate_size=2752, tie_word_embeddings=True)
+    c["vision_config"] = dict(c["vision_config"], out_hidden_size=2048)
+    return c
+
+
 def weight_specs(cfg):
     """[(name, shape, kind)] in a fixed order; kind in {linear, norm, bias, embed, head}."""
     vc, tc = cfg["vision_config"], cfg["text_config"]
@@ -97,18 +134,16 @@ def weight_specs(cfg):
     return specs
 
 
-def make_weights(cfg, seed=0, dtype=torch.float32):
-    """Deterministic weights.  Scales chosen so activations stay O(1) and logits are peaky
-    enough for stable argmax (top-1/top-2 margins are recorded with the goldens)."""
+def iter_weights(cfg, seed=0, dtype=torch.float32):
+    """(name, tensor) in weight_specs order, one tensor alive at a time (the full-depth fixture is 26 GB in fp32)."""
     g = torch.Generator().manual_seed(seed)
-    W = {}
     for name, shape, kind in weight_specs(cfg):
         if kind == "norm":
             w = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif kind == "bias":
             w = 0.05 * torch.randn(shape, generator=g)
         elif kind == "embed":
-            w = 0.5 * torch.randn(shape, generator=g)
+            w = cfg.get("fixture_embed_scale", 0.5) * torch.randn(shape, generator=g)
         elif kind == "head":
             w = (4.0 / shape[1] ** 0.5) * torch.randn(shape, generator=g)
         elif kind == "patch":
@@ -117,8 +152,13 @@ def make_weights(cfg, seed=0, dtype=torch.float32):
         else:
             w = (1.0 / shape[1] ** 0.5) * torch.randn(shape, generator=g)
         # round through bf16 so the fp32 and bf16 runs see identical parameter values
-        W[name] = w.to(torch.bfloat16).to(dtype)
-    return W
+        yield name, w.to(torch.bfloat16).to(dtype)
+
+
+def make_weights(cfg, seed=0, dtype=torch.float32):
+    """Deterministic weights.  Scales chosen so activations stay O(1) and logits are peaky
+    enough for stable argmax (top-1/top-2 margins are recorded with the goldens)."""
+    return dict(iter_weights(cfg, seed, dtype))
 
 
 def make_prompt(cfg, grids, n_text_pre=5, n_text_mid=3, n_text_post=6, seed=0):

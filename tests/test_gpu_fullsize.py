@@ -14,6 +14,14 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# Error envelope at TRUE depth and width, measured in the build container (golden G10, tools/make_golden.py g10: all 28 LLM
+# layers + 32 ViT blocks at the 7B widths): HF's own bf16 path against HF fp32 on the step logits, in units of the logits'
+# standard deviation.  tests/test_gpu_model.py::test_full_depth_true_width_vs_hf holds the engine to 2x this envelope against
+# HF-fp32; two engine paths that are both within 2E of the truth are within 4E of each other -- the bounds used below.
+E_REL = 0.0185          # relative L2
+E_MAX_SIGMA = 0.0754    # max |error| / std(logits)      (0.303 on logits of std 4.02)
+E_MEAN_SIGMA = 0.0147   # mean |error| / std(logits)     (0.059)
+
 
 @pytest.fixture(scope="module")
 def eng7b():
@@ -28,6 +36,14 @@ def eng7b():
     # std 0.02 keeps the random-init attention in its smooth regime (larger q/k weights make softmax an arg-max over
     # 4.5k keys, which amplifies bf16 noise chaotically); a wider lm_head gives logits with usable top-1/top-2 margins
     return O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 7, "cuda", std=0.02, head_std=0.08), "cuda"))
+
+
+@pytest.fixture(scope="module")
+def need_big_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if torch.cuda.get_device_properties(0).total_memory < 60e9:
+        pytest.skip("needs > 60 GB of HBM")
 
 
 def _prompt(cfg, n_frames, tpf, seed=0):
@@ -59,8 +75,9 @@ def test_fullsize_properties(eng7b):
     same = (full.argmax(-1).cpu() == seq[0, 4490:].cpu())
     # logits are bf16: two correct kernel families may differ by a few bf16 ulps of the logit magnitude
     scale = top2[:, 0].abs().cpu()
-    # (28 layers deep: measured path-to-path logit noise is up to ~0.4, vs 0.12-0.17 for HF-bf16 vs HF-fp32 at 3 layers)
-    tol = torch.clamp(4 * scale * 2.0 ** -8, min=0.6)
+    sigma = full.std().item()
+    # a choice is "safe" when its margin exceeds the largest path-to-path logit difference the envelope allows (4 E_max)
+    tol = torch.clamp(4 * scale * 2.0 ** -8, min=4 * E_MAX_SIGMA * sigma)
     safe = (margins > tol) & (pre_margin > tol)
     dec_logit_of_choice = full.gather(1, seq[0, 4490:, None].to(full.device))[:, 0].cpu()
     gap = (top2[:, 0].cpu() - dec_logit_of_choice)
@@ -80,10 +97,9 @@ def test_fullsize_properties(eng7b):
     d = (lg2 - full).abs().max().item()
     rel = ((lg2 - full).norm() / full.norm()).item()
     agree = (lg2.argmax(-1) == full.argmax(-1)).cpu()
-    print(f"P2: padded vs unpadded teacher-forced logits: rel-L2 {rel:.4f}, max|diff| {d:.3f} over {lg2.numel()} logits "
-          f"(|top logit| ~ {scale.median():.1f}), argmax agree {int(agree.sum())}/{T}")
-    # ~230 bf16 rounding points deep with random weights: a random walk of 2^-9 relative errors gives a few percent
-    assert rel < 0.06 and agree[pre_margin > tol].all()
+    print(f"P2: padded vs unpadded teacher-forced logits: rel-L2 {rel:.4f} (bound {4 * E_REL:.4f}), max|diff| {d:.3f} "
+          f"(bound {4 * E_MAX_SIGMA * sigma:.3f}) over {lg2.numel()} logits of std {sigma:.2f}, argmax agree {int(agree.sum())}/{T}")
+    assert rel < 4 * E_REL and d < 4 * E_MAX_SIGMA * sigma and agree[pre_margin > tol].all()
     both = eng.generate([r[:pad + 4490] for r in rows], [m[:pad + 4490] for m in mask],
                         frames=torch.cat([frames, frames.flip(0)]), max_new_tokens=4).sequences
     if margins[0] > 0.2:
@@ -126,13 +142,14 @@ def test_fullsize_reuse_paths(eng7b):
     eng.generate([other], None, frames=frames, max_new_tokens=1, prefix_key="vid")
     warm = eng.generate([ids], None, frames=frames, max_new_tokens=6, prefix_key="vid")
     assert warm.timings["prefix_tokens_reused"] == S - 15
-    if cold.margins[0, 0] > 0.6:
+    floor = 4 * E_MAX_SIGMA * eng.forward_logits(cold.sequences.cpu().numpy(), None, frames=frames)[0, S - 1:].float().std().item()
+    if cold.margins[0, 0] > floor:
         assert warm.sequences[0, S] == cold.sequences[0, S]
     m = min(cold.n_steps, warm.n_steps)
     differ = (warm.sequences[0, S:S + m] != cold.sequences[0, S:S + m]).nonzero()
     if differ.numel():      # the two runs may part ways only at a token whose top-1/top-2 margin is within the logit noise
         j = int(differ[0])
-        assert min(cold.margins[0, j].item(), warm.margins[0, j].item()) <= 0.6, f"prefix reuse changed a safe-margin token at step {j}"
+        assert min(cold.margins[0, j].item(), warm.margins[0, j].item()) <= floor, f"prefix reuse changed a safe-margin token at step {j}"
     eng.drop_prefix_cache()
     # P6
     grp = eng.generate([ids], None, frames=frames, max_new_tokens=6, num_return_sequences=16).sequences
@@ -144,9 +161,11 @@ def test_fullsize_reuse_paths(eng7b):
     seq0 = torch.cat([torch.tensor(ids), comp[2]])[None]
     full = eng.per_token_logps(eng.forward_logits(seq0.numpy(), None, frames=frames), seq0).cpu()[0, S - 1:]
     d = (lp[2] - full).abs()
-    print(f"P7: shared-prompt vs full-sequence log-probs: max|diff| {d.max():.4f}, mean|diff| {d.mean():.4f} (values ~ {full.mean():.2f})")
-    # same envelope as P2: with random 28-layer weights two correct summation orders differ by up to ~0.8 in a logit
-    assert d.max().item() < 1.0 and d.mean().item() < 0.3
+    sigma = eng.forward_logits(seq0.numpy(), None, frames=frames)[0, S - 1:].float().std().item()
+    # a log-prob is a logit minus a log-sum-exp of logits: twice the logit bound (4 E) of two paths
+    print(f"P7: shared-prompt vs full-sequence log-probs: max|diff| {d.max():.4f} (bound {8 * E_MAX_SIGMA * sigma:.3f}), "
+          f"mean|diff| {d.mean():.4f} (bound {8 * E_MEAN_SIGMA * sigma:.3f}); logits std {sigma:.2f}")
+    assert d.max().item() < 8 * E_MAX_SIGMA * sigma and d.mean().item() < 8 * E_MEAN_SIGMA * sigma
     # P8
     try:
         eng.w.vit.gemm_tile = eng.w.llm.gemm_tile = 128      # the descriptors carry the tile choice (0 = per shape)
@@ -156,3 +175,113 @@ def test_fullsize_reuse_paths(eng7b):
     finally:
         eng.w.vit.gemm_tile = eng.w.llm.gemm_tile = 0
     assert torch.equal(l128, lauto)
+
+
+def _decode_vs_prefill(eng, ids, frames, T):
+    """Greedy-decode T tokens (GEMV / decode-attention / fused-launch kernels), then run prompt+completion through the prefill
+    kernels (MFMA GEMM / flash attention) and compare, teacher-forced: the two kernel families must pick the same token
+    wherever both margins are safe.  Returns (output, n_safe, margin floor)."""
+    S = len(ids)
+    out = eng.generate([ids], None, frames=frames, max_new_tokens=T)
+    seq, margins = out.sequences, out.margins[0].cpu()
+    full = eng.forward_logits(seq.cpu().numpy(), None, frames=frames)[0, S - 1:-1].float()
+    top2 = full.topk(2, dim=-1).values
+    pre_margin = (top2[:, 0] - top2[:, 1]).cpu()
+    same = (full.argmax(-1).cpu() == seq[0, S:].cpu())
+    sigma = full.std().item()
+    tol = torch.clamp(4 * top2[:, 0].abs().cpu() * 2.0 ** -8, min=4 * E_MAX_SIGMA * sigma)   # margin floor from the G10 envelope
+    safe = (margins > tol) & (pre_margin > tol)
+    gap = top2[:, 0].cpu() - full.gather(1, seq[0, S:, None].to(full.device))[:, 0].cpu()
+    print(f"decode vs prefill at S={S}: {int(same.sum())}/{T} argmax agree, {int(safe.sum())} safe, max gap of a disagreeing choice "
+          f"{gap[~same].max().item() if (~same).any() else 0:.3f}")
+    assert same[safe].all() and (gap <= tol).all()
+    return out, int(safe.sum()), 4 * E_MAX_SIGMA * sigma
+
+
+def test_fused_decode_launch_equals_stand_alone_kernels_fullsize(eng7b):
+    """The one-launch attention block (csrc/o3v_fused.hip) against the three stand-alone launches through the whole engine at
+    the bench's size: 28 layers x 24 steps of hand-offs, greedy ids AND margins bit-identical."""
+    eng, cfg = eng7b, eng7b.cfg
+    F, H, W = 32, 224, 420
+    ids = _prompt(cfg, F, (H // 28) * (W // 28))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    assert eng.fused_decode
+    a = eng.generate([ids], None, frames=frames, max_new_tokens=24, repetition_penalty=1.05)
+    try:
+        eng.fused_decode = False
+        b = eng.generate([ids], None, frames=frames, max_new_tokens=24, repetition_penalty=1.05)
+    finally:
+        eng.fused_decode = True
+    assert torch.equal(a.sequences, b.sequences) and torch.equal(a.margins, b.margins)
+
+
+def test_long_video_256_frames(eng7b):
+    """BASELINE config #4: 256 frames 224x224 -> 16384 visual tokens, S = 20394.  Decode attention over the 64-way context
+    split, causal prefill tiles 160 K-tiles deep, and a prompt suffix prefilled behind 20k cached tokens (`past` offset in
+    the causal tiles): decode and prefill kernel families agree at safe margins, the cached-prefix run reproduces the cold
+    run's first token."""
+    eng, cfg = eng7b, eng7b.cfg
+    F, H, W = 256, 224, 224
+    tpf = (H // 28) * (W // 28)
+    ids = _prompt(cfg, F, tpf, seed=4)
+    S = len(ids)
+    assert S == 256 * (64 + 15) + 170
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    out, n_safe, floor = _decode_vs_prefill(eng, ids, frames, 10)
+    # a second question over the same video: only the last 40 tokens differ -> prefill of 40 rows behind S-40 cached keys
+    other = list(ids)
+    other[-40] = ids[-40] + 1
+    eng.drop_prefix_cache()
+    eng.generate([other], None, frames=frames, max_new_tokens=1, prefix_key="long")
+    warm = eng.generate([ids], None, frames=frames, max_new_tokens=4, prefix_key="long")
+    assert warm.timings["prefix_tokens_reused"] == S - 40
+    if out.margins[0, 0] > floor:
+        assert warm.sequences[0, S] == out.sequences[0, S]
+    eng.drop_prefix_cache()
+
+
+def test_eval_res_full_size(eng7b):
+    """EVAL-RES: 32 frames 364x644 -> grid 26x46, ragged windows of 12 / 16 / 48 / 64 patches, 9568 visual tokens,
+    S = 10218.  ViT bookkeeping (window permutation, per-frame full-attention segments of 1196 patches) as a property:
+    permuting the frames permutes the merged tokens bit for bit; decode and prefill agree at safe margins."""
+    eng, cfg = eng7b, eng7b.cfg
+    F, H, W = 32, 364, 644
+    tpf = (H // 28) * (W // 28)
+    assert tpf == 299
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    px, grid = eng.pixels_from_frames(frames[:5])
+    v1 = eng.vit_forward(px, grid).view(5, tpf, -1)
+    perm = torch.tensor([3, 0, 4, 1, 2], device="cuda")
+    px2, grid2 = eng.pixels_from_frames(frames[:5][perm])
+    v2 = eng.vit_forward(px2, grid2).view(5, tpf, -1)
+    assert torch.equal(v2, v1[perm]) and torch.isfinite(v1.float()).all()
+    ids = _prompt(cfg, F, tpf, seed=7)
+    assert len(ids) == 32 * (299 + 15) + 170
+    _decode_vs_prefill(eng, ids, frames, 8)
+
+
+def test_3b_dims_tied_head(need_big_gpu):
+    """BASELINE config #1 shapes on the GPU: Qwen2.5-VL-3B dimensions (36 layers of 2048 / 11008, 16 query / 2 kv heads, TIED
+    word embeddings, vocabulary 151936), 4 frames 364x644, 32 new tokens: decode and prefill kernel families agree at safe
+    margins, the fused launch equals the stand-alone kernels bit for bit, the head reads the embedding matrix."""
+    from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, random_getter
+    cfg = O3VConfig.from_dict(qwen25vl_3b_dict())
+    assert cfg.text.tie_word_embeddings
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 11, "cuda", std=0.02, head_std=0.08), "cuda"))
+    assert eng.w.t["l.head"].data_ptr() == eng.w.t["l.embed"].data_ptr()
+    F, H, W = 4, 364, 644
+    ids = _prompt(cfg, F, 299, seed=8)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    a, _, _ = _decode_vs_prefill(eng, ids, frames, 32)
+    try:
+        eng.fused_decode = False
+        b = eng.generate([ids], None, frames=frames, max_new_tokens=32)
+    finally:
+        eng.fused_decode = True
+    assert torch.equal(a.sequences, b.sequences) and torch.equal(a.margins, b.margins)

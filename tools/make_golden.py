@@ -292,6 +292,87 @@ def g6_g7():
     np.savez_compressed(os.path.join(GOLD, "g7_medium.npz"), **r)
 
 
+def hf_model_streamed(cfg, seed):
+    """HF fp32 model whose parameters are filled one tensor at a time from fm.iter_weights (no second copy of the 26 GB of
+    the full-depth fixture is ever alive), random initialisation skipped."""
+    from transformers.initialization import no_init_weights
+    with no_init_weights():
+        m = Qwen2_5_VLForConditionalGeneration(hf_config(cfg)).eval()
+    params = dict(m.named_parameters())
+    seen = set()
+    with torch.no_grad():
+        for name, w in fm.iter_weights(cfg, seed):
+            params[name].copy_(w)
+            seen.add(name)
+    left = [n for n in params if n not in seen]
+    assert not left or (cfg.get("tie_word_embeddings") and left == ["lm_head.weight"]), left
+    if cfg.get("tie_word_embeddings"):
+        m.tie_weights()
+    return m
+
+
+def to_bf16_keep_rotary(m):
+    keep = {n: b.clone() for n, b in m.named_buffers() if "inv_freq" in n}
+    m = m.to(torch.bfloat16)
+    for n, b in keep.items():
+        setattr(m.get_submodule(n.rsplit(".", 1)[0]), n.rsplit(".", 1)[1], b)
+    return m
+
+
+def deep_case(cfg, wseed, frames, n_new, prompt_seed, n_text_pre=5, n_text_post=6):
+    """fp32 then bf16 (the SAME module converted in place) greedy generation: ids, step logits, margins, merged visual tokens."""
+    pv, grid = preprocess_frames(frames)
+    ids = fm.make_prompt(cfg, [tuple(g) for g in grid.tolist()], n_text_pre=n_text_pre, n_text_post=n_text_post, seed=prompt_seed)
+    ids_t = torch.tensor([ids])
+    mask = torch.ones_like(ids_t)
+    types = (ids_t == cfg["image_token_id"]).int()
+    res = {"frames": frames.numpy(), "pixel_values": pv.numpy(), "grid": grid.numpy(), "input_ids": ids_t.numpy()}
+    m = hf_model_streamed(cfg, wseed)
+    for dname in ("f32", "bf16"):
+        if dname == "bf16":
+            m = to_bf16_keep_rotary(m)
+        dt = torch.float32 if dname == "f32" else torch.bfloat16
+        with torch.no_grad():
+            vo = m.model.visual(pv.to(dt), grid_thw=grid)
+            gen = m.generate(input_ids=ids_t, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
+                             mm_token_type_ids=types, do_sample=False, max_new_tokens=n_new, output_logits=True,
+                             return_dict_in_generate=True, eos_token_id=None, pad_token_id=cfg["pad_token_id"],
+                             repetition_penalty=1.0, temperature=None, top_p=None, top_k=None)
+        step_logits = torch.stack(gen.logits, dim=1).float()
+        top2 = step_logits.topk(2, dim=-1).values
+        res[f"{dname}_vit_merged"] = vo.pooler_output.float().numpy()
+        res[f"{dname}_ids"] = gen.sequences.numpy()
+        res[f"{dname}_step_logits"] = step_logits.numpy()
+        res[f"{dname}_margins"] = (top2[..., 0] - top2[..., 1]).numpy()
+        res[f"{dname}_rope_deltas"] = m.model.rope_deltas.numpy()
+        print(f"  {dname}: ids {gen.sequences[0, -n_new:].tolist()} margins {res[f'{dname}_margins'][0].round(3).tolist()}", flush=True)
+    d = np.abs(res["bf16_step_logits"] - res["f32_step_logits"])
+    print(f"  HF bf16 vs fp32 step logits: max {d.max():.4f} mean {d.mean():.4f}; |logit| max {np.abs(res['f32_step_logits']).max():.2f}")
+    return res
+
+
+def g10_full_depth():
+    """All 28 LLM layers and 32 ViT blocks at the true 7B widths (fm.full7b_config: vocabulary 4096), 2 frames 112x168
+    (grid 8x12: one 64- and one 32-patch window per frame), ~70 prompt tokens, 6 greedy tokens."""
+    cfg = fm.full7b_config()
+    r = deep_case(cfg, 3, fm.make_frames(2, 112, 168, seed=0), 6, prompt_seed=0)
+    np.savez_compressed(os.path.join(GOLD, "g10_full7b.npz"), **r)
+    print("G10 written")
+
+
+def g11_tied():
+    """Tied word embeddings + GQA 8:1 at head_dim 128 (fm.tied3b_config, the 3B family's distinguishing features)."""
+    cfg = fm.tied3b_config()
+    for s in range(50):
+        r = deep_case(cfg, 4, fm.make_frames(2, 112, 140, seed=s), 12, prompt_seed=s)
+        if (r["f32_ids"] == r["bf16_ids"]).all() and min(r["f32_margins"].min(), r["bf16_margins"].min()) > 0.2:
+            r["case_seed"] = np.asarray([s])
+            np.savez_compressed(os.path.join(GOLD, "g11_tied3b.npz"), **r)
+            print("G11 written, seed", s)
+            return
+    raise RuntimeError("no robust seed for G11")
+
+
 def g8_logits_processors():
     from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
                                                         TopPLogitsWarper)
@@ -364,6 +445,10 @@ if __name__ == "__main__":
         g8_logits_processors()
     if "g8b" in which:
         g8b_top_k()
+    if "g10" in which:
+        g10_full_depth()
+    if "g11" in which:
+        g11_tied()
 
 
 # ------------------------------------------------------------------------------------------------ G9 rewards / spans
