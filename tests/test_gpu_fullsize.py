@@ -182,7 +182,12 @@ def _decode_vs_prefill(eng, ids, frames, T):
     kernels (MFMA GEMM / flash attention) and compare, teacher-forced: the two kernel families must pick the same token
     wherever both margins are safe.  Returns (output, n_safe, margin floor)."""
     S = len(ids)
-    out = eng.generate([ids], None, frames=frames, max_new_tokens=T)
+    ids = list(ids)
+    for attempt in range(6):
+        out = eng.generate([ids], None, frames=frames, max_new_tokens=T)
+        if not (out.sequences[0, S:] == eng.cfg.image_token_id).any():
+            break
+        ids[-1] += 1   # random-init weights drew the image placeholder as a token: it cannot be teacher-forced; vary the prompt
     seq, margins = out.sequences, out.margins[0].cpu()
     full = eng.forward_logits(seq.cpu().numpy(), None, frames=frames)[0, S - 1:-1].float()
     top2 = full.topk(2, dim=-1).values
@@ -230,13 +235,13 @@ def test_long_video_256_frames(eng7b):
     gen = torch.Generator(device="cuda").manual_seed(5)
     frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
     out, n_safe, floor = _decode_vs_prefill(eng, ids, frames, 10)
-    # a second question over the same video: only the last 40 tokens differ -> prefill of 40 rows behind S-40 cached keys
+    # a second question over the same video: only the last 15 tokens differ -> prefill of 15 rows behind S-15 cached keys
     other = list(ids)
-    other[-40] = ids[-40] + 1
+    other[-15] = ids[-15] + 1
     eng.drop_prefix_cache()
     eng.generate([other], None, frames=frames, max_new_tokens=1, prefix_key="long")
     warm = eng.generate([ids], None, frames=frames, max_new_tokens=4, prefix_key="long")
-    assert warm.timings["prefix_tokens_reused"] == S - 40
+    assert warm.timings["prefix_tokens_reused"] == S - 15
     if out.margins[0, 0] > floor:
         assert warm.sequences[0, S] == out.sequences[0, S]
     eng.drop_prefix_cache()
