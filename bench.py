@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the GSPO rollout leg (G=8 sampled + log-probs + all_gather)")
     ap.add_argument("--rollout-tokens", type=int, default=768)
     ap.add_argument("--launch-check", action="store_true", help="CPU-only: join the world over gloo and print its size")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weight decode measurement")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -409,14 +410,36 @@ def main():
         batched = {"videos_per_step": NB, "tokens_per_s_per_gpu": round(NB * args.new_tokens / tb, 1),
                    "videos_per_min_per_gpu": round(NB / tb * 60.0, 1), "ms_per_step": round(tb * 1e3, 1)}
     roof = None if (args.no_roofline or rank != 0) else kernel_roofline(eng)
+    fused_flag = eng.fused_decode
+    wbytes = sum(eng.w.t[f"l{l}.{k}"].numel() * 2 for l in range(cfg.text.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
+    wbytes += eng.w.t["l.head"].numel() * 2
+
+    # extra (not `value`, which stays bf16): the same decode on fp8 (OCP e4m3fn) weight rows with per-row scales -- BASELINE
+    # config #5's weight format; half the weight bytes per step
+    fp8 = None
+    if not args.no_fp8 and rank == 0:
+        del eng
+        torch.cuda.empty_cache()
+        eng8 = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=False, fp8_decode=True))
+        kw8 = dict(max_new_tokens=args.new_tokens, eos_token_ids=(), repetition_penalty=1.05, return_margins=False)
+        eng8.generate([ids], None, frames=videos[0], **kw8)
+        t8 = eng8.generate([ids], None, frames=videos[1], sync_timings=True, **kw8).timings
+        tc8 = cfg.text
+        wb8 = sum(eng8.w.t[f"l{l}.{k}8"].numel() for l in range(tc8.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
+        wb8 += eng8.w.t["l.head8"].numel()
+        kvb = 2 * tc8.num_hidden_layers * tc8.num_key_value_heads * tc8.head_dim * 2 * (S + args.new_tokens / 2)
+        ms8 = t8["decode_ms"] / args.new_tokens
+        fp8 = {"weights": "fp8 e4m3fn rows + f32 power-of-two scale per output row, activations / KV / accumulation as in bf16",
+               "decode_ms_per_step": round(ms8, 4), "decode_tokens_per_s": round(1e3 / ms8, 1),
+               "algorithmic_bytes": int(wb8 + kvb), "achieved_GBps": round((wb8 + kvb) / (ms8 * 1e-3) / 1e9, 1),
+               "frac_of_8TBps": round((wb8 + kvb) / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del eng8
 
     if rank == 0:
         n_gpus = dist.get_world_size() if dist else 1
         total_tokens = n_gpus * args.steps * args.new_tokens
         ms_per_step = dt / args.steps * 1e3
         tc = cfg.text
-        wbytes = sum(eng.w.t[f"l{l}.{k}"].numel() * 2 for l in range(tc.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
-        wbytes += eng.w.t["l.head"].numel() * 2
         kv_bytes = 2 * tc.num_hidden_layers * tc.num_key_value_heads * tc.head_dim * 2 * (S + args.new_tokens / 2)
         dec_ms = stages.get("decode_ms", 0.0) / max(1, args.new_tokens)
         par = f"dp{n_gpus} (replica per GPU, independent videos, no data-path collective in the headline leg)"
@@ -436,7 +459,7 @@ def main():
             "decode_step_hbm": {"algorithmic_bytes": int(wbytes + kv_bytes), "ms": round(dec_ms, 4),
                                 "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
                                 "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None,
-                                "launches_per_layer": 4 if eng.fused_decode else 6},
+                                "launches_per_layer": 4 if fused_flag else 6},
         }
         if roll:
             rec["rollout"] = roll
@@ -444,6 +467,8 @@ def main():
             rec["batched_videos"] = batched
         if roof:
             rec["roofline"] = roof
+        if fp8:
+            rec["fp8_decode"] = fp8
         if not args.no_cpu_baseline and n_gpus == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg_dict, args.frames, Hres, Wres, S, args.new_tokens)
             rec["cpu_baseline"]["config1_full"] = cpu_baseline_config1()

@@ -118,6 +118,17 @@ int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* 
                       const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
                       o3v_stream_t stream);
 
+/* Decode linears on fp8 (OCP e4m3fn) weights, M <= 3 rows: W8 uint8 [N, K] (K % 16 == 0) with one fp32 scale per output
+ * row; out = epi(scale[n] * (rmsnorm(X; norm_w) . fp8(W8[n])) + bias), x and the accumulation as in the bf16 path (the fp8
+ * values are widened to bf16 exactly, v_cvt_scalef32_pk_bf16_fp8, and meet x in v_dot2c_f32_bf16).  Same epilogues. */
+int o3v_linear_decode_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale, const void* bias,
+                          const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
+                          o3v_stream_t stream);
+int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,
+                               const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT, void* qout,
+                               void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
+                               int cs_off, o3v_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------------------------- */
 /* tiles: int32[n_tiles][8] = {q_row0, q_rows (<= rows_per_tile), k_row0, k_len, causal_off, k_lo, batch, 0};
  * rows_per_tile 64 (ragged ViT windows) or 128 (prefill).
@@ -149,12 +160,20 @@ int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* o
  * the fused form: call the three stand-alone entries instead. */
 #define O3V_SYNC_TMO_BYTE 2048
 size_t o3v_decode_sync_bytes(void);
-int o3v_decode_attn_block_capacity(int h, int qd); /* workgroups of the fused kernel resident at once; 0: shape not built */
+int o3v_decode_attn_block_capacity(int qd, int wb); /* workgroups of the fused kernel resident at once; 0: shape not built */
 int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
                           const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
                           float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax,
                           int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
                           o3v_stream_t stream);
+
+/* o3v_decode_attn_block on fp8 (OCP e4m3fn) rows + per-row scales for the q/k/v and o projections (bit-identical to
+ * o3v_gemv_norm_qkv_rope_fp8 + o3v_attn_decode + o3v_linear_decode_fp8) */
+int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, const void* qkv_w8, const float* qkv_s, const void* qkv_b,
+                              const void* o_w8, const float* o_s, const void* cosT, const void* sinT, void* q_buf, void* att_buf,
+                              void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv,
+                              int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
+                              uint32_t epoch, o3v_stream_t stream);
 
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,
@@ -209,6 +228,10 @@ typedef struct {
     const void* down_w;          /* [H, I] */
     /* optional MFMA-fragment-major copies of the four matrices for the M >= 2 decode path (NULL = row-major only) */
     const void *qkv_wp, *o_wp, *gu_wp, *down_wp;
+    /* optional fp8 (OCP e4m3fn) copies of the four matrices, same row layouts, with one fp32 scale per output row
+     * (NULL = bf16 only): the batch <= 3 decode streams these instead -- half the bytes (o3v_linear_decode_fp8) */
+    const void *qkv_w8, *o_w8, *gu_w8, *down_w8;
+    const float *qkv_s, *o_s, *gu_s, *down_s;
 } o3v_llm_layer_w;
 
 typedef struct {
@@ -220,6 +243,8 @@ typedef struct {
     const void* lm_head;         /* [vocab, H] (== embed when tied) */
     const void* lm_head_p;       /* optional fragment-major copy of lm_head */
     int gemm_tile;               /* 0 = per shape; 128 / 256 = force that GEMM kernel in the prefill (tests) */
+    const void* lm_head8;        /* optional fp8 copy of lm_head + per-row scales (decode, <= 3 rows) */
+    const float* lm_head_s;
 } o3v_llm_desc;
 
 size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P);

@@ -28,13 +28,14 @@ class VitDesc(C.Structure):
 
 
 class LlmLayerW(C.Structure):
-    _fields_ = [(n, vp) for n in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w", "qkv_wp", "o_wp", "gu_wp", "down_wp")]
+    _fields_ = [(n, vp) for n in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w", "qkv_wp", "o_wp", "gu_wp", "down_wp",
+                                  "qkv_w8", "o_w8", "gu_w8", "down_w8", "qkv_s", "o_s", "gu_s", "down_s")]
 
 
 class LlmDesc(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
                 ("vocab", i32), ("rms_eps", f32), ("embed", vp), ("layer", C.POINTER(LlmLayerW)), ("final_norm", vp),
-                ("lm_head", vp), ("lm_head_p", vp), ("gemm_tile", i32)]
+                ("lm_head", vp), ("lm_head_p", vp), ("gemm_tile", i32), ("lm_head8", vp), ("lm_head_s", vp)]
 
 
 class DecodeState(C.Structure):
@@ -70,11 +71,15 @@ SIGNATURES = {
     "o3v_attn_decode_group": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "o3v_decode_sync_bytes": [],
     "o3v_decode_attn_block_capacity": [i32, i32],
+    "o3v_decode_attn_block_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                  i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_decode_attn_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                               i32, f32, vp, C.c_uint32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_linear_decode_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_gemv_norm_qkv_rope_fp8": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_norm_bf16": [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_sample_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, u64, vp, i32, i32, vp, vp],
@@ -115,7 +120,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
             fn.argtypes = args
             fn.restype = _RET.get(name, i32)
-        if lib.o3v_abi_version() != 3:
+        if lib.o3v_abi_version() != 4:
             raise O3VError("libo3v_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -50,7 +50,7 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
-extern "C" int o3v_abi_version(void) { return 3; }
+extern "C" int o3v_abi_version(void) { return 4; }
 
 // ------------------------------------------------------------------------------------------------ ViT
 extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
@@ -205,6 +205,9 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
         return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
                                  d->vocab, 0, O3V_EPI_NONE, s);
     }
+    if (rows <= 3 && d->lm_head8)  // fp8 head (decode with fp8 weights): half the 1.09 GB
+        return o3v_linear_decode_fp8(x, d->final_norm, d->rms_eps, d->lm_head8, d->lm_head_s, nullptr, nullptr, logits, rows,
+                                     d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
     if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
         return o3v_linear_decode(x, d->final_norm, d->rms_eps, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows,
                                  d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
@@ -241,6 +244,8 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // launches per layer), B=8 4.04 -> 3.97, B=16 5.63 -> 5.25: taken from B=8 on.
     const bool norm_apart = B >= 8;
     // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
+    // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
+    const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
     bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
     int step = step0;
     // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
@@ -248,7 +253,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         const o3v_llm_layer_w& lw = d->layer[l];
         char* kc = (char*)st->kcache + l * layer_stride;
         char* vc = (char*)st->vcache + l * layer_stride;
-        if (norm_apart) {
+        if (fp8) {
+            TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
+                                           kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+        } else if (norm_apart) {
             TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
             TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
                                        st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
@@ -262,7 +270,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         else
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1, st->Tmax,
                                 st->nsplit, scale, s));
-        TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        if (fp8)
+            TRY(o3v_linear_decode_fp8(w.att, nullptr, 0.f, lw.o_w8, lw.o_s, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        else
+            TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
         return O3V_OK;
     };
     for (int i = 0; i < n_steps; ++i) {
@@ -284,16 +295,27 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
             if (fused) {
-                const int rc = o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q,
-                                                     w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step,
-                                                     st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync,
-                                                     (uint32_t)(step * d->layers + l + 1), s);
+                const uint32_t epoch = (uint32_t)(step * d->layers + l + 1);
+                const int rc =
+                    fp8 ? o3v_decode_attn_block_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, lw.o_w8, lw.o_s, st->cosT,
+                                                    st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D,
+                                                    st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync, epoch, s)
+                        : o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,
+                                                vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step, st->Tmax, st->Tnew,
+                                                step, st->nsplit, scale, st->sync, epoch, s);
                 if (rc == O3V_ERR_SHAPE && l == 0)
                     fused = false;  // shapes or residency do not allow the one-launch form: the stand-alone kernels instead
                 else if (rc != O3V_OK)
                     return rc;
             }
             if (!fused) TRY(attention_half(l));
+            if (fp8) {
+                TRY(o3v_linear_decode_fp8(st->x, lw.ln2, d->rms_eps, lw.gu_w8, lw.gu_s, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
+                                          O3V_EPI_SWIGLU, s));
+                TRY(o3v_linear_decode_fp8(w.mlp, nullptr, 0.f, lw.down_w8, lw.down_s, nullptr, st->x, st->x, B, H, I, I, H, H,
+                                          O3V_EPI_RESIDUAL, s));
+                continue;
+            }
             if (norm_apart) {
                 TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,

@@ -37,7 +37,8 @@ constexpr int SYNC_WORDS = (32 + 512 + 512) * O3V_SYNC_STRIDE;
 constexpr int ATTN_LDS = 4 * 32 * 288;                 // attn_decode_mfma_body: 4 V slices (merge + combine scratch inside)
 
 struct FusedArgs {
-    const bf16_t *x, *ln_w, *qkv_w, *qkv_b, *o_w;
+    const bf16_t *x, *ln_w, *qkv_w, *qkv_b, *o_w;   // qkv_w / o_w: bf16 rows, or fp8 rows (WB = 1) with the scales below
+    const float *qkv_s, *o_s;
     bf16_t *att, *xout;
     float* part_o;
     float* part_ml;
@@ -59,21 +60,24 @@ struct FusedArgs {
 #define O3V_STAMP_PTR(a) nullptr
 #endif
 
-// o_proj + residual for two rows per wave; NSTEP = 512-wide k steps of the row (all held in registers).
-// Same accumulation order as gemv_body<1, 2, 1, EPI_RESIDUAL, false>: chunk lane + 64 i, i ascending, then the wave sum.
-template <int NSTEP>
+// o_proj + residual for two rows per wave; NSTEP = steps of 64 16-byte weight chunks per row (all held in registers), WB =
+// bytes per weight (2 bf16, 1 fp8 + row scale).  Same accumulation order as gemv_body<1, 2, 1, EPI_RESIDUAL, false, ..., WB>:
+// chunk lane + 64 i, i ascending, then the wave sum.
+template <int NSTEP, int WB>
 __device__ __forceinline__ void oproj_role(const FusedArgs& a, const int bid) {
+    constexpr int XPC = 2 / WB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = a.ra.Hq * a.ra.D, N = a.H, nch = K >> 3;
+    const int K = a.ra.Hq * a.ra.D, N = a.H, nch = K >> (WB == 1 ? 4 : 3);
     int rows[2];
     const u32x4* wp[2];
-    float e_res[2];
+    float e_res[2], e_scale[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         rows[r] = (bid * 4 + wave) * 2 + r;
         const int rr = rows[r] < N ? rows[r] : N - 1;
-        wp[r] = reinterpret_cast<const u32x4*>(a.o_w + (size_t)rr * K);
+        wp[r] = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.o_w) + (size_t)rr * K * WB);
         e_res[r] = bf2f(a.x[rr]);  // residual stream: written by an earlier launch
+        e_scale[r] = WB == 1 ? a.o_s[rr] : 1.0f;
     }
     u32x4 wv[NSTEP][2];
     auto load_weights = [&]() {
@@ -109,40 +113,48 @@ __device__ __forceinline__ void oproj_role(const FusedArgs& a, const int bid) {
     if (a.knob & 8) load_weights();
 #endif
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.att, 0, K * 2, 0x00020000);
-    u32x4 xv[NSTEP];
+    u32x4 xv[NSTEP][XPC];
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
         const int c = i * 64 + lane;
-        xv[i] = load16_sc1(xrs, (uint32_t)(c < nch ? c : 0) * 16);  // lanes past the row meet zeroed weights
+#pragma unroll
+        for (int h = 0; h < XPC; ++h)
+            xv[i][h] = load16_sc1(xrs, (uint32_t)((c < nch ? c : 0) * XPC + h) * 16);  // lanes past the row meet zeroed weights
     }
     float acc[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) fma8(wv[i][r], xv[i], acc[r]);
+        for (int r = 0; r < 2; ++r) {
+            if constexpr (WB == 1)
+                fma16_fp8(wv[i][r], xv[i][0], xv[i][XPC - 1], acc[r]);
+            else
+                fma8(wv[i][r], xv[i][0], acc[r]);
+        }
 #pragma unroll
     for (int r = 0; r < 2; ++r) acc[r] = wave_sum(acc[r]);
     if (lane != 0) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         if (rows[r] >= N) continue;
-        float v = acc[r] + 0.f;  // no bias (TF:620)
+        float v = acc[r] * e_scale[r] + 0.f;  // no bias (TF:620); bf16 rows: scale 1
         v = rbf(v) + e_res[r];
         a.xout[rows[r]] = f2bf(v);
     }
 }
 
-// NH / NSTEP: 512-wide k steps of a q/k/v row (K = H) / of an o_proj row (K = Hq*D).  (Requesting a q/k/v row pair's whole
-// weight stream in one trip was measured and dropped: no faster, and 170+ VGPRs.)
-template <int NH, int NSTEP>
+// NSTEP: steps of 64 16-byte weight chunks of an o_proj row (K = Hq*D; 512 k per step in bf16, 1024 in fp8); WB: bytes per
+// weight of the two projections.  (Requesting a q/k/v row pair's whole weight stream in one trip was measured and dropped:
+// no faster, and 170+ VGPRs.)
+template <int NSTEP, int WB>
 __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     const int Hq = a.ra.Hq, Hkv = a.ra.Hkv, D = a.ra.D, n_rep = Hq / Hkv;
     O3V_STAMP(O3V_STAMP_PTR(a), 0);
     if (bid < a.nb_qkv) {
-        gemv_body<1, 2, 1, EPI_QKVROPE, true, true>(a.x, a.qkv_w, a.qkv_b, nullptr, nullptr, a.ln_w, a.eps, (Hq + 2 * Hkv) * D, a.H,
-                                                    a.H, a.H, 0, 0, a.ra, bid, smem);
+        gemv_body<1, 2, 1, EPI_QKVROPE, true, true, 0, 4, WB>(a.x, a.qkv_w, a.qkv_b, nullptr, nullptr, a.ln_w, a.eps,
+                                                              (Hq + 2 * Hkv) * D, a.H, a.H, a.H, 0, 0, a.ra, bid, smem, a.qkv_s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
         __syncthreads();
         if (threadIdx.x < 64) {  // wave 0: ticket; the last workgroup of the kv head tells that head's attention workgroups
@@ -182,17 +194,17 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
                                     a.nsplit, hk, 0, smem, ho);
         return;
     }
-    oproj_role<NSTEP>(a, bid - a.nb_qkv - a.nb_attn);
+    oproj_role<NSTEP, WB>(a, bid - a.nb_qkv - a.nb_attn);
     O3V_STAMP(O3V_STAMP_PTR(a), 3);
 }
 
 // workgroups of this kernel the chip holds at once (0: query failed)
-template <int NH, int NSTEP>
+template <int NSTEP, int WB>
 int fused_capacity(size_t shmem) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_block_kernel<NH, NSTEP>, 256, shmem) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_block_kernel<NSTEP, WB>, 256, shmem) != hipSuccess) return 0;
     // the query can over-report for SGPR-heavy kernels, never below 6 workgroups per CU (MI355X_MICROARCH.md, Residency)
     if (per_cu > 6) per_cu = 6;
     return per_cu * prop.multiProcessorCount;
@@ -200,14 +212,15 @@ int fused_capacity(size_t shmem) {
 
 }  // namespace
 
-// (NH, NSTEP) pairs built: 7B (3584 / 3584), 3B (2048 / 2048), 8B-class (4096 / 4096), test fixtures (896 / 1792)
-#define O3V_FUSED_SHAPES(X) X(7, 7) X(4, 4) X(8, 8) X(2, 4)
+// o_proj row lengths built (steps of 64 chunks): bf16 rows of 1792 (fixtures) / 2048 (3B) / 3584 (7B) / 4096 (8B class) take
+// 4 / 4 / 7 / 8 steps, their fp8 forms 2 / 2 / 4 / 4
+#define O3V_FUSED_SHAPES(X) X(7, 2) X(4, 2) X(8, 2) X(2, 1) X(4, 1)
 
-// workgroups of the fused kernel the chip holds at once for hidden size h and o_proj rows of qd = Hq*D (diagnostics / tests)
-extern "C" int o3v_decode_attn_block_capacity(int h, int qd) {
-    const int nh = (h / 8 + 63) / 64, nq = (qd / 8 + 63) / 64;
+// workgroups of the fused kernel the chip holds at once for o_proj rows of qd = Hq*D elements of wb bytes (diagnostics / tests)
+extern "C" int o3v_decode_attn_block_capacity(int qd, int wb) {
+    const int nq = (qd / (wb == 1 ? 16 : 8) + 63) / 64;
 #define O3V_X(A, B) \
-    if (nh == A && nq == B) return fused_capacity<A, B>(ATTN_LDS);
+    if (nq == A && wb == B) return fused_capacity<A, B>(ATTN_LDS);
     O3V_FUSED_SHAPES(O3V_X)
 #undef O3V_X
     return 0;
@@ -222,11 +235,13 @@ extern "C" void o3v_fused_set_knob(int k) { g_knob = k; }
 
 extern "C" size_t o3v_decode_sync_bytes(void) { return (size_t)SYNC_WORDS * 4; }
 
-extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
-                                     const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
-                                     float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot,
-                                     int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
-                                     uint32_t epoch, hipStream_t stream) {
+static int attn_block_launch(void* x, const void* ln_w, float eps, const void* qkv_w, const float* qkv_s, const void* qkv_b,
+                             const void* o_w, const float* o_s, const void* cosT, const void* sinT, void* q_buf, void* att_buf,
+                             void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv,
+                             int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
+                             uint32_t epoch, hipStream_t stream) {
+    const int wb = qkv_s ? 1 : 2;
+    if ((qkv_s == nullptr) != (o_s == nullptr)) return O3V_ERR_ARG;
     if (!x || !ln_w || !qkv_w || !o_w || !cosT || !sinT || !q_buf || !att_buf || !kcache || !vcache || !part_o || !part_ml ||
         !sync || epoch == 0 || slot < 0 || slot >= Tmax || H <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || nsplit <= 0 || nsplit > 64)
         return O3V_ERR_ARG;
@@ -238,8 +253,11 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
     if (nb_attn > 512 || nb_o > 512) return O3V_ERR_SHAPE;  // mailbox lines
     const size_t lds_qkv = (size_t)H * 2 + 4 * 2 * 4 + 4 * 4;
     const size_t shmem = lds_qkv > (size_t)ATTN_LDS ? lds_qkv : (size_t)ATTN_LDS;
-    const int nstep = (QD / 8 + 63) / 64;
+    if (wb == 1 && ((H & 15) || (QD & 15))) return O3V_ERR_SHAPE;
+    const int nstep = (QD / (wb == 1 ? 16 : 8) + 63) / 64;
     FusedArgs a;
+    a.qkv_s = qkv_s;
+    a.o_s = o_s;
     a.x = (const bf16_t*)x;
     a.ln_w = (const bf16_t*)ln_w;
     a.qkv_w = (const bf16_t*)qkv_w;
@@ -267,10 +285,9 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
     a.knob = g_knob;
 #endif
     const dim3 grid(nb_qkv + nb_attn + nb_o), block(256);
-    const int nh = (H / 8 + 63) / 64;
     bool launched = false;
 #define O3V_X(A, B)                                                                                      \
-    if (!launched && nh == A && nstep == B) {                                                            \
+    if (!launched && nstep == A && wb == B) {                                                            \
         static const int cap = fused_capacity<A, B>(shmem);                                              \
         if (nb_attn + nb_o >= cap) return O3V_ERR_SHAPE; /* waiting workgroups must not fill the chip */ \
         O3V_KLAUNCH((decode_attn_block_kernel<A, B>), grid, block, shmem, stream, a);                    \
@@ -281,4 +298,24 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
     if (!launched) return O3V_ERR_SHAPE;
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
+                                     const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
+                                     float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot,
+                                     int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
+                                     uint32_t epoch, hipStream_t stream) {
+    return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, cosT, sinT, q_buf, att_buf, kcache, vcache, part_o,
+                             part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync, epoch, stream);
+}
+
+// the same with fp8 (OCP e4m3fn) rows + per-row scales for the two projections (o3v_linear_decode_fp8's weight format)
+extern "C" int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, const void* qkv_w8, const float* qkv_s,
+                                         const void* qkv_b, const void* o_w8, const float* o_s, const void* cosT, const void* sinT,
+                                         void* q_buf, void* att_buf, void* kcache, void* vcache, float* part_o, float* part_ml,
+                                         const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax, int cs_stride_row,
+                                         int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch, hipStream_t stream) {
+    if (!qkv_s || !o_s) return O3V_ERR_ARG;
+    return attn_block_launch(x, ln_w, eps, qkv_w8, qkv_s, qkv_b, o_w8, o_s, cosT, sinT, q_buf, att_buf, kcache, vcache, part_o,
+                             part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync, epoch, stream);
 }

@@ -364,14 +364,15 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------
 // Small-M weight-streaming GEMV (decode): body in o3v_gemv_body.h (shared with the fused decode launch).
 // ------------------------------------------------------------------------------------------------
-template <int M, int R, int KS, int EPI, bool NORM, int NW = 4>
+template <int M, int R, int KS, int EPI, bool NORM, int NW = 4, int WB = 2>
 __global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                             bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
                                                             float eps, int N, int K, int ldx, int ldw, int ldo, int ldr,
-                                                            RopeArgs ra) {
+                                                            RopeArgs ra, const float* __restrict__ wscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M*K bf16] [KS>1: NW*R*M f32] [NORM: NW*M f32]
-    gemv_body<M, R, KS, EPI, NORM, false, 0, NW>(X, W, bias, res, out, norm_w, eps, N, K, ldx, ldw, ldo, ldr, ra, blockIdx.x, smem);
+    gemv_body<M, R, KS, EPI, NORM, false, 0, NW, WB>(X, W, bias, res, out, norm_w, eps, N, K, ldx, ldw, ldo, ldr, ra, blockIdx.x, smem,
+                                                     wscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,9 +630,10 @@ struct GemvArgs {
     hipStream_t s;
     RopeArgs ra;
     bool packed;  // W points at the MFMA-fragment-major image (M >= 2 path only)
+    const float* wscale = nullptr;  // fp8 weights (M <= 3): one dequantisation scale per output row; W then points at bytes
 };
 
-template <int M, int R, int KS, bool NORM, int NW = 4>
+template <int M, int R, int KS, bool NORM, int NW = 4, int WB = 2>
 int launch_gemv(const GemvArgs& a) {
     const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : (a.epi == EPI_QKVROPE ? 1 : R);
     const int outs = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 2 : a.N;
@@ -640,8 +642,8 @@ int launch_gemv(const GemvArgs& a) {
     const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)NW * R * M * 4 + (NORM ? NW * M * 4 : 0);
     if (shmem > 160 * 1024) return O3V_ERR_SHAPE;
 #define O3V_GV(E)                                                                                                             \
-    O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM, NW>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,  \
-                a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra)
+    O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM, NW, WB>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, \
+                a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, a.wscale)
     switch (a.epi) {
         case EPI_QKVROPE:
             if (R != 2 || !NORM) return O3V_ERR_ARG;  // the rotary pair (j, j+D/2) is the wave's two rows
@@ -668,7 +670,7 @@ extern "C" void o3v_gemv_tune(int R, int KS) {
 // R = 2 rows per wave, KS K-slices: pick the waves per workgroup so that the grid is a whole number of workgroups per CU
 // (MI355X: 256 CUs).  Measured at 7B dims (profiles/r02_gemv_balance.txt): down_proj 896 x 4 waves (3.5 per CU) -> 256 x 14,
 // o_proj 448 x 4 (1.75 per CU) -> 256 x 7, q/k/v 576 x 4 (2.25 per CU) -> 768 x 3.
-template <int M, int KS, bool NORM>
+template <int M, int KS, bool NORM, int WB = 2>
 int launch_gemv_balanced(const GemvArgs& a) {
     if constexpr (M == 1) {
         constexpr int CUS = 256;
@@ -678,25 +680,25 @@ int launch_gemv_balanced(const GemvArgs& a) {
             const int per_cu = waves / CUS;
             if constexpr (KS == 1) {
                 switch (per_cu) {
-                    case 3: case 6: case 9: case 12: return launch_gemv<M, 2, 1, NORM, 3>(a);
-                    case 5: case 10: case 15: return launch_gemv<M, 2, 1, NORM, 5>(a);
-                    case 7: case 14: return launch_gemv<M, 2, 1, NORM, 7>(a);
+                    case 3: case 6: case 9: case 12: return launch_gemv<M, 2, 1, NORM, 3, WB>(a);
+                    case 5: case 10: case 15: return launch_gemv<M, 2, 1, NORM, 5, WB>(a);
+                    case 7: case 14: return launch_gemv<M, 2, 1, NORM, 7, WB>(a);
                     default: break;
                 }
             } else {
                 switch (per_cu) {
-                    case 6: case 12: return launch_gemv<M, 2, 2, NORM, 6>(a);
-                    case 10: return launch_gemv<M, 2, 2, NORM, 10>(a);
-                    case 14: return launch_gemv<M, 2, 2, NORM, 14>(a);
+                    case 6: case 12: return launch_gemv<M, 2, 2, NORM, 6, WB>(a);
+                    case 10: return launch_gemv<M, 2, 2, NORM, 10, WB>(a);
+                    case 14: return launch_gemv<M, 2, 2, NORM, 14, WB>(a);
                     default: break;
                 }
             }
         }
     }
-    return launch_gemv<M, 2, KS, NORM>(a);
+    return launch_gemv<M, 2, KS, NORM, 4, WB>(a);
 }
 
-template <int M, bool NORM>
+template <int M, bool NORM, int WB = 2>
 int launch_gemv_m(const GemvArgs& a) {
 #ifdef O3V_TUNE
     if (g_tune_R) {
@@ -708,16 +710,17 @@ int launch_gemv_m(const GemvArgs& a) {
 #endif
     // Decomposition: enough waves to keep >= 32 KiB of weight loads in flight per CU, whole 512-k steps per wave.
     const int outs = (a.epi == EPI_SWIGLU) ? a.N / 2 : a.N;
-    const int steps = (a.K / 8 + 63) / 64;
+    const int steps = (a.K / (WB == 1 ? 16 : 8) + 63) / 64;
     // decompositions chosen by interleaved A/B on MI355X (tools/tune_gemv.py, profiles/r01_gemv_tune.txt)
-    if (a.epi == EPI_QKVROPE) return launch_gemv_balanced<M, 1, NORM>(a);
+    if (a.epi == EPI_QKVROPE) return launch_gemv_balanced<M, 1, NORM, WB>(a);
     if (a.epi == EPI_SWIGLU) {
-        if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM>(a);  // 2 (gate,up) pairs per wave
-        return launch_gemv<M, 2, 1, NORM>(a);
+        // (fp8 rows, half as long: 4 pairs per wave measured slower, 1.958 vs 1.864 ms per decode step at 7B dims)
+        if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);  // 2 (gate,up) pairs per wave
+        return launch_gemv<M, 2, 1, NORM, 4, WB>(a);
     }
-    if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM>(a);     // lm_head
-    if (steps >= 16) return launch_gemv_balanced<M, 2, NORM>(a);           // long K (down_proj): split K over wave pairs
-    return launch_gemv_balanced<M, 1, NORM>(a);                            // o_proj / qkv
+    if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);     // lm_head
+    if (steps >= 16) return launch_gemv_balanced<M, 2, NORM, WB>(a);           // long K (down_proj): split K over wave pairs
+    return launch_gemv_balanced<M, 1, NORM, WB>(a);                            // o_proj / qkv
 }
 
 }  // namespace
@@ -914,7 +917,8 @@ static int launch_gemv_mfma(const GemvArgs& a, int M) {
 
 static int gemv_dispatch(const void* X, const void* W, const void* bias, const void* res, void* out, const void* norm_w,
                          float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
-                         hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr) {
+                         hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr,
+                         const float* wscale = nullptr) {
     if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 16) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
@@ -922,6 +926,20 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
     if (M == 0) return O3V_OK;
     GemvArgs a{(const bf16_t*)X, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w,
                (bf16_t*)out, eps, N, K, ldx, ldw, ldo, ldr, epilogue, stream, ra ? *ra : RopeArgs{}, false};
+    if (wscale) {
+        // fp8 (e4m3fn) weight rows + per-row scales: the scalar weight-streaming path, up to 3 rows of x
+        if (M > 3 || (K & 15) || (ldw & 15)) return O3V_ERR_SHAPE;
+        a.wscale = wscale;
+        int rc8;
+        switch (M) {
+            case 1: rc8 = norm_w ? launch_gemv_m<1, true, 1>(a) : launch_gemv_m<1, false, 1>(a); break;
+            case 2: rc8 = norm_w ? launch_gemv_m<2, true, 1>(a) : launch_gemv_m<2, false, 1>(a); break;
+            default: rc8 = norm_w ? launch_gemv_m<3, true, 1>(a) : launch_gemv_m<3, false, 1>(a); break;
+        }
+        if (rc8 != O3V_OK) return rc8;
+        O3V_CHECK_LAUNCH();
+        return O3V_OK;
+    }
     // with the fragment-major weight image every wave-instruction of the matrix-core path reads one contiguous KiB;
     // on row-major weights its 64-byte row segments cost ~25 % of the bandwidth
     // (M = 2, 3: the scalar dot2 GEMV still streams at ~5.8 TB/s, measured in profiles/r01_m8_linear.txt)
@@ -996,4 +1014,26 @@ extern "C" int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float e
                 slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
     return gemv_dispatch(X, W, bias, nullptr, nullptr, norm_w, eps, M, (Hq + 2 * Hkv) * D, K, ldx, K, 0, 0, EPI_QKVROPE, stream,
                          &ra, Wp);
+}
+
+// ---- fp8 (OCP e4m3fn) weights with one fp32 scale per output row, M <= 3 rows: the decode linears at half the bytes.
+// W8: uint8 [N, K] (K % 16 == 0), scale: f32 [N]; out = epi(scale[n] * (rmsnorm(X) . fp8(W8[n])) + bias).
+extern "C" int o3v_linear_decode_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,
+                                     const void* bias, const void* res, void* out, int M, int N, int K, int ldx, int ldo,
+                                     int ldr, int epilogue, hipStream_t stream) {
+    if (!scale) return O3V_ERR_ARG;
+    return gemv_dispatch(X, W8, bias, res, out, norm_w, eps, M, N, K, ldx, K, ldo, ldr, epilogue, stream, nullptr, nullptr, scale);
+}
+
+extern "C" int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,
+                                          const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT,
+                                          void* qout, void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax,
+                                          int cs_stride_row, int cs_off, hipStream_t stream) {
+    if (!scale || !norm_w || !cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 ||
+        (D & 1))
+        return O3V_ERR_ARG;
+    RopeArgs ra{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache,
+                slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
+    return gemv_dispatch(X, W8, bias, nullptr, nullptr, norm_w, eps, M, (Hq + 2 * Hkv) * D, K, ldx, K, 0, 0, EPI_QKVROPE, stream,
+                         &ra, nullptr, scale);
 }

@@ -37,6 +37,24 @@ __device__ __forceinline__ void fma8(const u32x4& w, const u32x4& x, float& acc)
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w3), __builtin_bit_cast(bf16x2_t, x3), acc, false);
 }
 
+// 16 fp8 (OCP e4m3fn) weights x 16 bf16 of x -> fp32 accumulate: v_cvt_scalef32_pk_bf16_fp8 widens two fp8 to two bf16
+// EXACTLY (3 mantissa bits fit in 7; scale 1.0), then the same v_dot2c_f32_bf16 as the bf16 path.  8 cvt + 8 dot2 per 16
+// weight bytes; the per-row dequantisation scale multiplies the finished sum.
+__device__ __forceinline__ void fma16_fp8(const u32x4& w, const u32x4& xa, const u32x4& xb, float& acc) {
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    const uint32_t x0 = xa[0], x1 = xa[1], x2 = xa[2], x3 = xa[3], x4 = xb[0], x5 = xb[1], x6 = xb[2], x7 = xb[3];
+#define O3V_F8(WW, XL, XH)                                                                                                   \
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(WW, 1.0f, false),                        \
+                                          __builtin_bit_cast(bf16x2_t, XL), acc, false);                                    \
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(WW, 1.0f, true),                         \
+                                          __builtin_bit_cast(bf16x2_t, XH), acc, false);
+    O3V_F8(w0, x0, x1)
+    O3V_F8(w1, x2, x3)
+    O3V_F8(w2, x4, x5)
+    O3V_F8(w3, x6, x7)
+#undef O3V_F8
+}
+
 struct RopeArgs {  // EPI_QKVROPE destinations (one token per row m, cache slot `slot`, table row m*cs_stride+cs_off)
     const bf16_t *cosT, *sinT;
     bf16_t *qout, *kc, *vc;
@@ -61,18 +79,24 @@ __device__ __forceinline__ void gemv_store_bf16(bf16_t* p, bf16_t v) {
 // the chip's rate only when every CU gets the same number of weight rows: the launcher picks NW so that the grid is a whole
 // number of workgroups per CU (e.g. o_proj at 7B: 1792 waves = 7 per CU -> NW 7, one workgroup per CU).  The rows of a
 // wave and their sums do not depend on NW; only the fused RMSNorm's sum of squares is split over NW waves.
-template <int M, int R, int KS, int EPI, bool NORM, bool PUB = false, int UU = 0, int NW = 4>
+// WB = bytes per weight element: 2 = bf16 rows; 1 = fp8 (OCP e4m3fn) rows with one fp32 dequantisation scale per output row
+// (`wscale`): a 16-byte weight chunk then spans 16 k (two 16-byte chunks of x) and the row's sum is multiplied by its scale
+// before the bias.  K % 16 == 0 for WB == 1.
+template <int M, int R, int KS, int EPI, bool NORM, bool PUB = false, int UU = 0, int NW = 4, int WB = 2>
 __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                           bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w, float eps, int N,
                                           int K, int ldx, int ldw, int ldo, int ldr, const RopeArgs& ra, const int bid,
-                                          char* smem) {
+                                          char* smem, const float* __restrict__ wscale = nullptr) {
     static_assert(NW % KS == 0, "K slices must divide the waves of a workgroup");
+    static_assert(WB == 1 || WB == 2, "bf16 or fp8 weights");
     constexpr int RG = NW / KS;                                  // row groups per block
     constexpr int NT = NW * 64;                                  // threads per block
+    constexpr int XPC = 2 / WB;                                  // 16-byte chunks of x per 16-byte chunk of weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = wave / KS, ks = wave % KS;
-    const int nch = K >> 3;
+    const int nch = K >> (WB == 1 ? 4 : 3);                      // weight chunks per row
+    const int nxc = K >> 3;                                      // x chunks per row
 
     // ---- rows of this wave.  SWIGLU: R/2 output columns = R/2 (gate,up) row pairs of the 16-row-interleaved weight
     const int grp = bid * RG + rg;
@@ -98,10 +122,13 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int rr = rows[r] < N ? rows[r] : N - 1;  // tail rows re-read a valid row, never stored
-        wp[r] = reinterpret_cast<const u32x4*>(W + (size_t)rr * ldw);
+        wp[r] = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(W) + (size_t)rr * ldw * WB);
     }
     // Epilogue operands (bias, residual, rotary cos/sin) are requested here, a whole kernel ahead of their use: these
     // kernels live for 7-25 us, and a dependent L2 round trip at the tail is 5-10 % of that.
+    float e_scale[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) e_scale[r] = (WB == 1) ? wscale[rows[r] < N ? rows[r] : N - 1] : 1.0f;
     float e_bias[R], e_res[EPI == EPI_RESIDUAL ? R : 1][EPI == EPI_RESIDUAL ? M : 1], e_cos[EPI == EPI_QKVROPE ? M : 1],
         e_sin[EPI == EPI_QKVROPE ? M : 1];
 #pragma unroll
@@ -132,7 +159,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 
     // weight loads of one trip (U steps x R rows, 16 B per lane each): issued as early as possible
     u32x4 wv[U][R];
-    u32x4 xg[NORM ? 1 : U][NORM ? 1 : M];  // un-normalised x comes from global memory (L2): fetched one trip ahead, with the weights
+    u32x4 xg[NORM ? 1 : U][NORM ? 1 : M][XPC];  // un-normalised x comes from global memory (L2): fetched one trip ahead, with the weights
     auto load_x = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -140,7 +167,10 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
             const int cc = c < c_end ? c : c_begin;
 #pragma unroll
             for (int m = 0; m < M; ++m)
-                xg[NORM ? 0 : u][NORM ? 0 : m] = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)cc * 8);
+#pragma unroll
+                for (int h = 0; h < XPC; ++h)
+                    xg[NORM ? 0 : u][NORM ? 0 : m][h] =
+                        *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + ((size_t)cc * XPC + h) * 8);
         }
     };
     auto load_w = [&](int c0) {
@@ -163,7 +193,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         // x (a few KiB, L2-resident) is requested first, then the first trip of weight loads, so that the
         // HBM latency of the weights runs under the norm instead of after it.
         constexpr int XC = (512 + NT - 1) / NT;      // x chunks per thread kept in registers (K <= 4096)
-        const bool small = (nch <= XC * NT) && (M <= 4);
+        const bool small = (nxc <= XC * NT) && (M <= 4);
         u32x4 xr[XC][M <= 4 ? M : 1], wnr[XC];  // x chunks and the norm-weight chunks that go with them: one latency, not two
         float ss[M];
 #pragma unroll
@@ -174,8 +204,8 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 const int c = threadIdx.x + i * NT;
 #pragma unroll
                 for (int m = 0; m < (M <= 4 ? M : 1); ++m)
-                    xr[i][m] = c < nch ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
-                wnr[i] = c < nch ? *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+                    xr[i][m] = c < nxc ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+                wnr[i] = c < nxc ? *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
             }
         }
         if (c_begin < c_end) load_w(c_begin);
@@ -190,7 +220,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                         ss[m] = fmaf(bf_hi(xr[i][m][j]), bf_hi(xr[i][m][j]), ss[m]);
                     }
         } else {
-            for (int c = threadIdx.x; c < nch; c += NT) {
+            for (int c = threadIdx.x; c < nxc; c += NT) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
@@ -229,13 +259,13 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
             for (int i = 0; i < XC; ++i) {
                 const int c = threadIdx.x + i * NT;
-                if (c < nch) {
+                if (c < nxc) {
 #pragma unroll
                     for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[i][m], wnr[i]);
                 }
             }
         } else {
-            for (int c = threadIdx.x; c < nch; c += NT) {
+            for (int c = threadIdx.x; c < nxc; c += NT) {
                 const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
 #pragma unroll
                 for (int m = 0; m < M; ++m)
@@ -254,21 +284,29 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 
     for (int c0 = c_begin; c0 < c_end; c0 += 64 * U) {
-        u32x4 xv[U][M];
+        u32x4 xv[U][M][XPC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + u * 64 + lane;
             const int cc = c < c_end ? c : c_begin;  // out-of-range lanes meet zeroed weights
 #pragma unroll
             for (int m = 0; m < M; ++m)
-                xv[u][m] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + (size_t)cc * 8) * 2) : xg[NORM ? 0 : u][NORM ? 0 : m];
+#pragma unroll
+                for (int h = 0; h < XPC; ++h)
+                    xv[u][m][h] = NORM ? *reinterpret_cast<const u32x4*>(smem + ((size_t)m * K + ((size_t)cc * XPC + h) * 8) * 2)
+                                       : xg[NORM ? 0 : u][NORM ? 0 : m][h];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int m = 0; m < M; ++m) fma8(wv[u][r], xv[u][m], acc[r][m]);
+                for (int m = 0; m < M; ++m) {
+                    if constexpr (WB == 1)
+                        fma16_fp8(wv[u][r], xv[u][m][0], xv[u][m][XPC - 1], acc[r][m]);
+                    else
+                        fma8(wv[u][r], xv[u][m][0], acc[r][m]);
+                }
         if (c0 + 64 * U < c_end) load_w(c0 + 64 * U);
     }
 #pragma unroll
@@ -297,6 +335,12 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
             }
     }
     if (lane != 0) return;
+    if (WB == 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[r][m] *= e_scale[r];
+    }
     if (EPI == EPI_QKVROPE) {
         if (rows[0] >= N) return;
         const int half = ra.D >> 1, head = rows[0] / ra.D, j = rows[0] % ra.D;

@@ -46,6 +46,28 @@ def pack_mfma_fragments(w: torch.Tensor) -> torch.Tensor:
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+FP8_MAX = 448.0   # largest finite OCP e4m3fn value
+
+
+def quantize_rows_fp8(w: torch.Tensor):
+    """[N, K] bf16 -> (uint8 [N, K] holding OCP e4m3fn codes, f32 [N] scales): per output row the scale is the smallest POWER
+    OF TWO s with max|w| / s <= 448, q = rne(w / s) (torch's float8_e4m3fn conversion; no overflow); an all-zero row gets
+    s = 1.  A power-of-two scale costs no precision (fp8 is floating point: it only shifts the exponent) and makes the
+    dequantised weight fp8(q) * s exactly representable in bf16, so the fp8 path can be checked against the bf16 path on the
+    very same weight values.  dequantize_rows_fp8 restates what the kernel multiplies."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1)
+    s = torch.exp2(torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / FP8_MAX)))
+    s = torch.where(amax > 0, s, torch.ones_like(s))
+    s = torch.where(amax / s > FP8_MAX, s * 2, s)          # guard the log2 rounding at exact powers of two
+    q = (wf / s[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), s.contiguous()
+
+
+def dequantize_rows_fp8(q8: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    return q8.view(torch.float8_e4m3fn).float() * s[:, None].float()
+
+
 def pad_cols(w: torch.Tensor, kpad: int) -> torch.Tensor:
     if w.shape[1] == kpad:
         return w.contiguous()
@@ -72,9 +94,12 @@ class _Getter:
 class DeviceWeights:
     """Owns the packed tensors and the ctypes descriptors that point at them."""
 
-    def __init__(self, cfg: O3VConfig, get: Callable[[str], torch.Tensor], device="cuda", batched_decode: bool = True):
+    def __init__(self, cfg: O3VConfig, get: Callable[[str], torch.Tensor], device="cuda", batched_decode: bool = True,
+                 fp8_decode: bool = False):
         """batched_decode: also keep MFMA-fragment-major copies of the LLM matrices (+1x their size in HBM) so that
-        decoding 2..8 sequences together (group rollout) streams weights at the same rate as batch 1."""
+        decoding 2..8 sequences together (group rollout) streams weights at the same rate as batch 1.
+        fp8_decode: also keep fp8 (OCP e4m3fn) copies of the LLM matrices and the head with one fp32 scale per output row
+        (quantize_rows_fp8); decode at batch <= 3 then streams those -- half the bytes per step (BASELINE config #5)."""
         self.cfg = cfg
         self.device = torch.device(device)
         g = _Getter(get, self.device)
@@ -141,6 +166,12 @@ class DeviceWeights:
                 if batched_decode and w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
                     keep[f"l{i}.{f}p"] = pack_mfma_fragments(w)
                     setattr(self.llm_layers[i], f + "p", keep[f"l{i}.{f}p"].data_ptr())
+            if fp8_decode:
+                for f in ("qkv_w", "o_w", "gu_w", "down_w"):
+                    q8, sc = quantize_rows_fp8(keep[f"l{i}.{f}"])
+                    keep[f"l{i}.{f}8"], keep[f"l{i}.{f}8s"] = q8, sc
+                    setattr(self.llm_layers[i], f[:-1] + "w8", q8.data_ptr())
+                    setattr(self.llm_layers[i], f[:-2] + "_s", sc.data_ptr())
         keep["l.norm"] = l("norm.weight").contiguous()
         if tc.tie_word_embeddings:
             keep["l.head"] = keep["l.embed"]
@@ -158,6 +189,10 @@ class DeviceWeights:
                                 vocab=tc.vocab_size, rms_eps=tc.rms_norm_eps, embed=keep["l.embed"].data_ptr(),
                                 layer=self.llm_layers, final_norm=keep["l.norm"].data_ptr(),
                                 lm_head=keep["l.head"].data_ptr(), lm_head_p=head_p)
+        self.fp8_decode = bool(fp8_decode)
+        if fp8_decode:
+            keep["l.head8"], keep["l.head8s"] = quantize_rows_fp8(keep["l.head"])
+            self.llm.lm_head8, self.llm.lm_head_s = keep["l.head8"].data_ptr(), keep["l.head8s"].data_ptr()
         self._check_shapes()
 
     def _check_shapes(self):

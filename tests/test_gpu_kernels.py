@@ -829,3 +829,102 @@ def test_sample_top_k_top_p(dev, V, top_k, top_p, temp, rep):
     ref_lp = torch.log_softmax(model_ref.top_k_warp(sc, top_k)[0], dim=-1)[o.view(-1)].view(B, N)   # softmax over what top-k kept
     assert (lp.cpu() - ref_lp).abs().max().item() < 2e-3
     assert len({tuple(r.tolist()) for r in o}) > 1 or int(kept.sum()) == 1
+
+
+@pytest.mark.parametrize("M", [1, 2, 3])
+@pytest.mark.parametrize("N,K,epi_name,norm", [(4608, 3584, "none", True), (37888, 3584, "swiglu", True), (3584, 18944, "res", False),
+                                               (3584, 3584, "res", False), (152064, 3584, "none", True), (512, 128, "gelu", False),
+                                               (2304, 896, "swiglu", True), (6144, 4096, "none", True)])
+def test_linear_decode_fp8_weights(dev, M, N, K, epi_name, norm):
+    """o3v_linear_decode_fp8 (OCP e4m3fn weight rows + one fp32 scale per row) against an fp32 matmul over the SAME quantised
+    weights (weights.dequantize_rows_fp8: exactly what the kernel multiplies) with the bf16 path's rounding points, and the
+    quantiser itself against torch's float8_e4m3fn (bit-exact codes)."""
+    import ctypes as C
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import dequantize_rows_fp8, pack_gate_up, quantize_rows_fp8
+    g = torch.Generator().manual_seed(M * 5 + N)
+    x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    w[:, : K // 3] *= 4.0      # uneven magnitudes along k and across rows: the per-row scale has work to do
+    w[::7] *= 0.05
+    if epi_name == "swiglu":
+        w = pack_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous(), N // 2)
+    w = w.to(dev)
+    q8, sc = quantize_rows_fp8(w)
+    assert q8.dtype == torch.uint8 and sc.dtype == torch.float32 and sc.shape == (N,)
+    wd = dequantize_rows_fp8(q8, sc)
+    assert ((wd - w.float()).abs() <= sc[:, None] * 16.0).all()   # within half an e4m3 step of the top binade (32 scale units)
+    assert (torch.log2(sc) == torch.log2(sc).round()).all() and (w.float().abs().amax(dim=1) <= sc * 448).all()
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    epi = {"none": ops.EPI_NONE, "swiglu": ops.EPI_SWIGLU, "res": ops.EPI_RESIDUAL, "gelu": ops.EPI_GELU}[epi_name]
+    No = N // 2 if epi == ops.EPI_SWIGLU else N
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty(M, No, dtype=BF, device=dev)
+    use_bias = epi != ops.EPI_SWIGLU
+    _lib.call("o3v_linear_decode_fp8", P(x), P(nw) if norm else None, 1e-6, P(q8), P(sc), P(bias) if use_bias else None,
+              P(res) if epi == ops.EPI_RESIDUAL else None, P(out), M, N, K, K, No, N, epi, st)
+    from oracle import model_ref
+    xn = model_ref.rmsnorm(x.cpu(), nw.cpu(), 1e-6).to(dev) if norm else x
+    acc = xn.float() @ wd.t()
+    if epi == ops.EPI_SWIGLU:
+        a3 = acc.view(M, N // 32, 2, 16)
+        gate, up = rb(a3[:, :, 0].reshape(M, -1)), rb(a3[:, :, 1].reshape(M, -1))
+        ref = rb(torch.nn.functional.silu(gate)) * up
+    else:
+        ref = _epi_ref(acc, bias, res if epi == ops.EPI_RESIDUAL else None, epi)
+    close_bf16(out, ref, ulps=1, atol=2e-3, frac=0.999)
+
+
+@pytest.mark.parametrize("Hq,Hkv,H,ctx,Tmax,nsplit,pad", [(28, 4, 3584, 4491, 5002, 40, 0), (16, 2, 2048, 1500, 1732, 14, 5),
+                                                           (32, 8, 4096, 300, 512, 4, 0), (14, 2, 896, 33, 64, 1, 0)])
+def test_decode_attn_block_fp8_equals_three_launches(dev, Hq, Hkv, H, ctx, Tmax, nsplit, pad):
+    """o3v_decode_attn_block_fp8 == o3v_gemv_norm_qkv_rope_fp8 + o3v_attn_decode + o3v_linear_decode_fp8 BIT FOR BIT (the roles
+    instantiate the same device code with one-byte weights), two epochs on one sync buffer."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import quantize_rows_fp8
+    D, Tnew, step = 128, 7, 3
+    slot = ctx - 1
+    g = torch.Generator().manual_seed(Hq * 1000 + ctx + 1)
+    N, QD = (Hq + 2 * Hkv) * D, Hq * D
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    q8, qs = quantize_rows_fp8((torch.randn(N, H, generator=g) / math.sqrt(H)).to(BF).to(dev))
+    o8, os_ = quantize_rows_fp8((torch.randn(H, QD, generator=g) / math.sqrt(QD)).to(BF).to(dev))
+    bqkv = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    ang = torch.rand(1, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    kc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    vc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    k_lo = torch.tensor([pad], dtype=torch.int32, device=dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
+    part_o = torch.empty(Hq * 64 * D, dtype=torch.float32, device=dev)
+    part_ml = torch.empty(Hq * 64 * 2, dtype=torch.float32, device=dev)
+    q2, att2 = torch.zeros(1, Hq, D, dtype=BF, device=dev), torch.zeros(1, Hq, D, dtype=BF, device=dev)
+    k2, v2 = kc0.clone(), vc0.clone()
+    for rep in range(2):
+        x0 = (torch.randn(1, H, generator=g) * 2).to(BF).to(dev)
+        x1, q1, k1, v1 = x0.clone(), torch.zeros(1, Hq, D, dtype=BF, device=dev), kc0.clone(), vc0.clone()
+        att1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        po1, pm1 = torch.empty_like(part_o), torch.empty_like(part_ml)
+        _lib.call("o3v_gemv_norm_qkv_rope_fp8", P(x1), P(nw), 1e-6, P(q8), P(qs), P(bqkv), 1, H, H, P(cos), P(sin), P(q1), P(k1), P(v1),
+                  slot, Hq, Hkv, D, Tmax, Tnew, step, st)
+        _lib.call("o3v_attn_decode", P(q1), P(k1), P(v1), P(att1), P(po1), P(pm1), P(k_lo), 1, Hq, Hkv, D, ctx, Tmax, nsplit, scale, st)
+        _lib.call("o3v_linear_decode_fp8", P(att1), None, 0.0, P(o8), P(os_), None, P(x1), P(x1), 1, H, QD, QD, H, H, _lib.EPI_RESIDUAL, st)
+        x2 = x0.clone()
+        rc = lib.o3v_decode_attn_block_fp8(P(x2), P(nw), 1e-6, P(q8), P(qs), P(bqkv), P(o8), P(os_), P(cos), P(sin), P(q2), P(att2),
+                                           P(k2), P(v2), P(part_o), P(part_ml), P(k_lo), H, Hq, Hkv, D, slot, Tmax, Tnew, step, nsplit,
+                                           scale, P(sync), rep + 1, st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item()) == 0
+        assert torch.equal(q2.view(torch.int16), q1.view(torch.int16)) and torch.equal(k2.view(torch.int16), k1.view(torch.int16))
+        assert torch.equal(att2.view(torch.int16), att1.view(torch.int16)) and torch.equal(x2.view(torch.int16), x1.view(torch.int16))

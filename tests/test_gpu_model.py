@@ -388,3 +388,54 @@ def test_tied_embeddings_gqa8(need_gpu, golden_dir):
     d_hf = (torch.from_numpy(g["bf16_step_logits"]) - ref).abs().max().item()
     print(f"G11 tied head: step logits max|err| vs HF-fp32: ours {d_ours:.4f}, HF-bf16 {d_hf:.4f}")
     assert d_ours < LOGIT_ATOL and d_ours < 2.0 * d_hf + 0.02
+
+
+def test_fp8_decode_weights_engine(need_gpu):
+    """Decode on fp8 (OCP e4m3fn, power-of-two row scales) copies of the LLM matrices and the head (BASELINE config #5's
+    weight format) through the whole engine.  The fixture's LLM linears are first replaced by their own dequantised values,
+    which are exact in bf16, so three runs see identical weight values: (a) the CPU oracle in bf16, (b) this engine
+    streaming bf16 rows, (c) this engine streaming the fp8 rows + scales.  Greedy ids of (c) must equal (a) and (b) wherever
+    the oracle's top-1/top-2 margin is safe; (c)'s decode differs from (b)'s only by summation order."""
+    from oracle import model_ref
+    from open_o3_video_amd.config import O3VConfig
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, dequantize_rows_fp8, getter_from_dict, quantize_rows_fp8
+    cfg = fm.medium_config()
+    W = fm.make_weights(cfg, 6)
+    for k in list(W):
+        if k.startswith("model.language_model.layers.") and k.endswith("_proj.weight") or k == "lm_head.weight":
+            q8, sc = quantize_rows_fp8(W[k].to(torch.bfloat16))
+            W[k] = dequantize_rows_fp8(q8, sc)
+            assert torch.equal(W[k], W[k].to(torch.bfloat16).float())        # exact in bf16
+    frames = fm.make_frames(2, 112, 140, seed=3)
+    n_new = 12
+    c = O3VConfig.from_dict(cfg)
+    eng_bf = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda"))
+    eng_f8 = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda", fp8_decode=True))
+    assert eng_f8.w.fp8_decode and eng_f8.w.llm.lm_head8
+    px, grid = eng_bf.pixels_from_frames(frames)
+    ids = np.asarray([fm.make_prompt(cfg, [tuple(g) for g in grid.tolist()], seed=3)])
+    # oracle (bf16) on the processor-shaped pixel rows
+    from oracle import index_ref
+    mean = np.asarray(index_ref.CLIP_MEAN, dtype=np.float32)[None, :, None, None]
+    std = np.asarray(index_ref.CLIP_STD, dtype=np.float32)[None, :, None, None]
+    xf = ((frames.numpy().astype(np.float64) / 255.0).astype(np.float32) - mean) / std
+    pv, grid2 = index_ref.patchify_frames(xf.astype(np.float32))
+    ref, ref_logits = model_ref.generate(W, cfg, ids, None, torch.from_numpy(pv), grid2, n_new, dtype=torch.bfloat16,
+                                         pad_token_id=cfg["pad_token_id"], return_logits=True)
+    top2 = ref_logits.float().topk(2, dim=-1).values
+    margins = (top2[..., 0] - top2[..., 1])[0]
+    a = eng_bf.generate(ids, None, frames=frames, max_new_tokens=n_new, pad_token_id=cfg["pad_token_id"])
+    b = eng_f8.generate(ids, None, frames=frames, max_new_tokens=n_new, pad_token_id=cfg["pad_token_id"])
+    ga, gb, gr = (a.sequences[0, -n_new:].cpu().numpy(), b.sequences[0, -n_new:].cpu().numpy(), ref[0, -n_new:].numpy())
+    print(f"fp8 decode: oracle {gr.tolist()}\n   bf16 rows {ga.tolist()}\n   fp8 rows  {gb.tolist()}\n   oracle margins {np.round(margins.numpy(), 3).tolist()}")
+    for name, got in (("bf16 rows", ga), ("fp8 rows", gb)):
+        k = 0
+        while k < n_new and got[k] == gr[k]:
+            k += 1
+        assert k == n_new or margins[k] < 0.2, f"{name}: ids leave the oracle's at step {k} with a safe margin {margins[k]:.3f}"
+    # the two engines' own margins along the common prefix: same weights, different summation order only
+    k = int((ga == gb).cumprod().sum())
+    d = (a.margins[0, :k] - b.margins[0, :k]).abs().max().item() if k else 0.0
+    print(f"   margins bf16-rows vs fp8-rows over {k} common steps: max |diff| {d:.4f}")
+    assert d < LOGIT_ATOL
