@@ -147,3 +147,26 @@ def test_model_against_hf(golden_dir, fname, cfgf, wseed, n_new, dname):
     ids_rp = model_ref.generate(W, cfg, g["input_ids"], None, pv, g["grid"], n_new, dtype=dt,
                                 pad_token_id=cfg["pad_token_id"], rep_penalty=1.05)
     assert np.array_equal(ids_rp.numpy(), g[f"{dname}_ids_rp105"])
+
+
+@pytest.mark.parametrize("fname,cfgname,wseed", [("g12_q3_tiny.npz", "tiny_q3_config", 0), ("g13_q3_medium.npz", "medium_q3_config", 2)])
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_qwen3vl_oracle_against_hf(golden_dir, fname, cfgname, wseed, dname):
+    """oracle/model_ref_q3.py == transformers' Qwen3VLForConditionalGeneration (goldens G12 / G13: merged visual tokens, the
+    DeepStack features, step logits, greedy ids): bit-exact in bf16, 2e-5 in fp32, like the Qwen2.5-VL oracle."""
+    import fixture_models_q3 as fq
+    from oracle import model_ref_q3
+    g = np.load(os.path.join(golden_dir, fname))
+    cfg = getattr(fq, cfgname)()
+    W = fq.make_weights(cfg, wseed)
+    dt = torch.float32 if dname == "f32" else torch.bfloat16
+    n_new = g["f32_step_logits"].shape[1]
+    taps = {}
+    ids, step_logits = model_ref_q3.generate(W, cfg, g["input_ids"], None, torch.from_numpy(g["pixel_values"]), g["grid"], n_new,
+                                             dtype=dt, pad_token_id=cfg["pad_token_id"], return_logits=True, taps=taps)
+    tol = 2e-5 if dname == "f32" else 0.0
+    np.testing.assert_allclose(taps["vit_merged"].float().numpy(), g[f"{dname}_vit_merged"], atol=tol * 10, rtol=tol)
+    for j, d in enumerate(taps["deepstack"]):
+        np.testing.assert_allclose(d.float().numpy(), g[f"{dname}_deepstack_{j}"], atol=tol * 10, rtol=tol)
+    np.testing.assert_allclose(step_logits.numpy(), g[f"{dname}_step_logits"], atol=max(tol * 50, 0), rtol=tol)
+    assert np.array_equal(ids.numpy(), g[f"{dname}_ids"])
