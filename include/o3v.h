@@ -33,6 +33,7 @@ typedef struct ihipStream_t* o3v_stream_t; /* hipStream_t */
 #define O3V_EPI_NONE 0     /* out = bf16(acc + bias) */
 #define O3V_EPI_RESIDUAL 1 /* out = bf16(bf16(acc + bias) + res)                          TF:311-321, :733-755 */
 #define O3V_EPI_GELU 2     /* out = bf16(gelu_erf(bf16(acc + bias)))                       TF:141-145 merger */
+#define O3V_EPI_GELU_TANH 6 /* out = bf16(gelu_tanh(bf16(acc + bias)))   MFMA GEMM only   TF3:101-112 Qwen3-VL vision MLP */
 #define O3V_EPI_SWIGLU 3   /* out[:, j] = bf16(bf16(silu(gate_j)) * up_j); W rows packed by o3v 16-row interleave  TF:85-96,541-554 */
 
 int o3v_abi_version(void);
@@ -41,6 +42,9 @@ int o3v_abi_version(void);
 /* Qwen2_5_VLRMSNorm.forward, TF:65-79 */
 int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, int cols, int ld_in, int ld_out, float eps,
                 o3v_stream_t stream);
+/* nn.LayerNorm with bias over `cols` (TF3:122-135, :268-284): fp32 statistics, one rounding.  x,out bf16 [rows, ld]. */
+int o3v_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int cols, int ld_in, int ld_out, float eps,
+                  o3v_stream_t stream);
 /* apply_rotary_pos_emb_vision, TF:160-171, in place on the q,k thirds of qkv[P,3*H*D]; cos/sin fp32 [P,D/2] */
 int o3v_vit_rope(void* qkv, const float* cosT, const float* sinT, int P, int H, int D, o3v_stream_t stream);
 /* Qwen2_5_VLRotaryEmbedding.forward + mrope section select, TF:525-538, :590-596; pos int32 [3,T] */
@@ -50,6 +54,13 @@ int o3v_mrope_table(const int* pos, const float* inv_freq, const int* axis_of, v
 int o3v_qkv_rope_cache(const void* qkv, const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache,
                        int slot_base, int T, int tokens_per_row, int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
                        int cs_off, o3v_stream_t stream);
+/* The same with Qwen3-VL's per-head RMSNorm (weights q_norm, k_norm bf16 [D], eps) applied to the q and k heads before the
+ * rotation (TF3:480-484); D/16 must be a power of two. */
+int o3v_qkv_norm_rope_cache(const void* qkv, const void* q_norm, const void* k_norm, float eps, const void* cosT,
+                            const void* sinT, void* qout, void* kcache, void* vcache, int slot_base, int T, int tokens_per_row,
+                            int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, o3v_stream_t stream);
+/* DeepStack add (TF3:839-862): x[rows[i], :] = bf16(x[rows[i], :] + feat[src[i], :]), i < n; x, feat bf16 rows of `hidden`. */
+int o3v_add_rows(void* x, const int* rows, const int* src, const void* feat, int n, int hidden, o3v_stream_t stream);
 /* hidden_states[window_index] / [reverse_indices], TF:436-439, :464-466 */
 int o3v_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, o3v_stream_t stream);
 /* embed_tokens + masked_scatter of image embeds, TF:1206-1215 */
@@ -62,6 +73,9 @@ int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0, int Kp, o3
  * on frames [T,3,H,W] (uint8 or f32 0..255) as R:vision_process.py:279-318 returns them */
 int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
                  const float* std3, o3v_stream_t stream);
+/* The same for a `patch`-pixel patch (Qwen3-VL: 16; H, W multiples of 2*patch; Kp >= 6*patch*patch). */
+int o3v_patchify_ps(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, int patch, const float* mean3,
+                    const float* std3, o3v_stream_t stream);
 
 /* fetch_video's frame resize, R:src/r1-v/src/open_r1/vision_process.py:310-315 (torchvision resize, BICUBIC, antialias ==
  * ATen _upsample_bicubic2d_aa): src [planes,H_in,W_in] uint8 or f32 -> dst f32 [planes,H_out,W_out]; tmp f32
@@ -232,6 +246,9 @@ typedef struct {
      * (NULL = bf16 only): the batch <= 3 decode streams these instead -- half the bytes (o3v_linear_decode_fp8) */
     const void *qkv_w8, *o_w8, *gu_w8, *down_w8;
     const float *qkv_s, *o_s, *gu_s, *down_s;
+    /* Qwen3-VL (TF3:438-500): RMSNorm weights [D] applied per head to q and k before the rotation; NULL = none (Qwen2.5-VL).
+     * With them qkv_b is NULL (attention_bias false) and the decode runs q/k/v as linear + o3v_qkv_norm_rope_cache. */
+    const void *q_norm, *k_norm;
 } o3v_llm_layer_w;
 
 typedef struct {
@@ -254,6 +271,40 @@ int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P, const int*
                     const float* cosT, const float* sinT, const int* tiles_win, int n_tiles_win, const int* tiles_full,
                     int n_tiles_full, void* workspace, size_t ws_bytes, void* out, o3v_stream_t stream);
 
+/* ---- Qwen3-VL vision tower (Qwen3VLVisionModel.forward, TF3:606-737) */
+#define O3V_MAX_DEEPSTACK 8
+typedef struct {
+    const void *norm1_w, *norm1_b;  /* LayerNorm [hidden] */
+    const void *qkv_w, *qkv_b;      /* [3*heads*head_dim_pad, pad64(hidden)]: per head [36|0000|36|0000]-style padded rows */
+    const void *proj_w, *proj_b;    /* [hidden, heads*head_dim_pad] (zero columns at the padded dims) */
+    const void *norm2_w, *norm2_b;
+    const void *fc1_w, *fc1_b;      /* [inter_pad, pad64(hidden)] (zero rows past intermediate_size) */
+    const void *fc2_w, *fc2_b;      /* [hidden, inter_pad] */
+} o3v_vit3_block_w;
+typedef struct {
+    const void *norm_w, *norm_b;    /* LayerNorm over hidden (postshuffle 0) or hidden*merge_unit (postshuffle 1) */
+    const void *fc1_w, *fc1_b;      /* [hidden*unit, hidden*unit], GELU(erf) */
+    const void *fc2_w, *fc2_b;      /* [out_hidden, hidden*unit] */
+    int postshuffle;
+} o3v_vit3_merger_w;
+typedef struct {
+    int depth, hidden, heads, head_dim, head_dim_pad, inter_pad, out_hidden, patch_k_pad, merge_unit;
+    int n_deep;                       /* DeepStack taps */
+    int deep_index[O3V_MAX_DEEPSTACK];/* ascending block indexes (deepstack_visual_indexes) */
+    int gemm_tile;
+    const void *patch_w, *patch_b;    /* [hidden, patch_k_pad], [hidden] */
+    const o3v_vit3_block_w* blocks;   /* [depth] */
+    o3v_vit3_merger_w merger;
+    o3v_vit3_merger_w deep[O3V_MAX_DEEPSTACK];
+} o3v_vit3_desc;
+size_t o3v_vit3_workspace_bytes(const o3v_vit3_desc* d, int P);
+/* pixels bf16 [P, patch_k_pad] in merge-block order; pos_embed bf16 [P, hidden]: the learned position table interpolated to
+ * this grid (TF3:643-710, host side); cos/sin f32 [P, head_dim_pad/2]; tiles: one non-causal segment per temporal patch.
+ * out bf16 [P/unit, out_hidden]; deep_out bf16 [n_deep][P/unit, out_hidden]. */
+int o3v_vit3_forward(const o3v_vit3_desc* d, const void* pixels, int P, const void* pos_embed, const float* cosT,
+                     const float* sinT, const int* tiles, int n_tiles, void* workspace, size_t ws_bytes, void* out, void* deep_out,
+                     o3v_stream_t stream);
+
 size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 /* Qwen2_5_VLTextModel.forward over the prompt, TF:790-872: x bf16 [B*S,H] holds inputs_embeds on entry and the
  * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D].
@@ -263,6 +314,12 @@ size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
                     int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax, void* workspace,
                     size_t ws_bytes, o3v_stream_t stream);
+/* The same with DeepStack (Qwen3-VL, TF3:839-862): after decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]]
+ * for i < n_ds (the visual rows among this call's B*S rows); ds_feat: n_deep tables, ds_stride bf16 elements apart. */
+int o3v_llm_prefill_deepstack(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
+                              int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax, const int* ds_rows,
+                              const int* ds_src, int n_ds, const void* ds_feat, int n_deep, long ds_stride, void* workspace,
+                              size_t ws_bytes, o3v_stream_t stream);
 /* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
 int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                  o3v_stream_t stream);

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(HERE, "libo3v_hip.so")
 OK, ERR_ARG, ERR_SHAPE, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3, -4
 _ERR = {ERR_ARG: "bad argument", ERR_SHAPE: "unsupported shape", ERR_LAUNCH: "HIP launch failure",
         ERR_WORKSPACE: "workspace too small"}
-EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU = 0, 1, 2, 3
+EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU, EPI_GELU_TANH = 0, 1, 2, 3, 6
+MAX_DEEPSTACK = 8
 
 vp, ip, fp, i32, i64, f32, u64, sz = (C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_long,
                                       C.c_float, C.c_uint64, C.c_size_t)
@@ -29,7 +30,23 @@ class VitDesc(C.Structure):
 
 class LlmLayerW(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w", "qkv_wp", "o_wp", "gu_wp", "down_wp",
-                                  "qkv_w8", "o_w8", "gu_w8", "down_w8", "qkv_s", "o_s", "gu_s", "down_s")]
+                                  "qkv_w8", "o_w8", "gu_w8", "down_w8", "qkv_s", "o_s", "gu_s", "down_s", "q_norm", "k_norm")]
+
+
+class Vit3BlockW(C.Structure):
+    _fields_ = [(n, vp) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
+                                  "fc2_w", "fc2_b")]
+
+
+class Vit3MergerW(C.Structure):
+    _fields_ = [(n, vp) for n in ("norm_w", "norm_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("postshuffle", i32)]
+
+
+class Vit3Desc(C.Structure):
+    _fields_ = [("depth", i32), ("hidden", i32), ("heads", i32), ("head_dim", i32), ("head_dim_pad", i32), ("inter_pad", i32),
+                ("out_hidden", i32), ("patch_k_pad", i32), ("merge_unit", i32), ("n_deep", i32), ("deep_index", i32 * MAX_DEEPSTACK),
+                ("gemm_tile", i32), ("patch_w", vp), ("patch_b", vp), ("blocks", C.POINTER(Vit3BlockW)), ("merger", Vit3MergerW),
+                ("deep", Vit3MergerW * MAX_DEEPSTACK)]
 
 
 class LlmDesc(C.Structure):
@@ -51,6 +68,10 @@ class DecodeState(C.Structure):
 SIGNATURES = {
     "o3v_abi_version": [],
     "o3v_rmsnorm": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "o3v_layernorm": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "o3v_qkv_norm_rope_cache": [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_add_rows": [vp, vp, vp, vp, i32, i32, vp],
+    "o3v_patchify_ps": [vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp],
     "o3v_vit_rope": [vp, vp, vp, i32, i32, i32, vp],
     "o3v_mrope_table": [vp, vp, vp, vp, vp, i32, i32, vp],
     "o3v_qkv_rope_cache": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -90,10 +111,14 @@ SIGNATURES = {
     "o3v_vit_forward": [C.POINTER(VitDesc), vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, sz, vp, vp],
     "o3v_llm_workspace_bytes": [C.POINTER(LlmDesc), i32],
     "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp],
+    "o3v_vit3_workspace_bytes": [C.POINTER(Vit3Desc), i32],
+    "o3v_vit3_forward": [C.POINTER(Vit3Desc), vp, i32, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp],
+    "o3v_llm_prefill_deepstack": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64,
+                                  vp, sz, vp],
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }
-_RET = {"o3v_vit_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
+_RET = {"o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
 
 SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
 SAMPLE_SCRATCH_FLOATS = 40960   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h
@@ -120,7 +145,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
             fn.argtypes = args
             fn.restype = _RET.get(name, i32)
-        if lib.o3v_abi_version() != 4:
+        if lib.o3v_abi_version() != 5:
             raise O3VError("libo3v_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -43,6 +43,11 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// F.gelu(approximate="tanh") in fp32 (ATen's GeluKernel: kBeta = sqrt(2/pi), kKappa = 0.044715)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float inner = 0.79788456080286535588f * (x + 0.044715f * (x * x * x));
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
 
 // error codes of the C ABI (include/o3v.h)
 #define O3V_OK 0

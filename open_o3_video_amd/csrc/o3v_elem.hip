@@ -80,6 +80,89 @@ extern "C" int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm with bias (Qwen3-VL vision blocks and mergers, TF3:122-135, :268-284): fp32 statistics over the row held in
+// VGPRs (mean, then the centred sum of squares), y = (x - mean) * rstd * w + b, one rounding to bf16.
+// ------------------------------------------------------------------------------------------------
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int rows,
+                                                        int cols, int ld_in, int ld_out, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * ld_in);
+    uint4 v[MAXCH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = xr[c];
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += bf_lo(p[j]) + bf_hi(p[j]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)cols;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(p[j]) - mean, d = bf_hi(p[j]) - mean;
+                ss = fmaf(a, a, ss);
+                ss = fmaf(d, d, ss);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)cols + eps);
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    const uint4* br = reinterpret_cast<const uint4*>(b);
+    uint4* orow = reinterpret_cast<uint4*>(out + (size_t)row * ld_out);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const uint4 wv = wr[c], bv = br[c];
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv);
+            const uint32_t* z = reinterpret_cast<const uint32_t*>(&bv);
+            uint4 o;
+            uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                po[j] = pack_bf2((bf_lo(p[j]) - mean) * rstd * bf_lo(q[j]) + bf_lo(z[j]),
+                                 (bf_hi(p[j]) - mean) * rstd * bf_hi(q[j]) + bf_hi(z[j]));
+            orow[c] = o;
+        }
+    }
+}
+
+extern "C" int o3v_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int cols, int ld_in, int ld_out,
+                             float eps, hipStream_t stream) {
+    if (!x || !w || !b || !out || rows < 0 || cols <= 0 || (cols & 7) || (ld_in & 7) || (ld_out & 7)) return O3V_ERR_ARG;
+    if (rows == 0) return O3V_OK;
+    if (cols > 16 * 512) return O3V_ERR_SHAPE;
+    dim3 grid((rows + 3) / 4), block(256);
+#define O3V_LN(CH)                                                                                                        \
+    O3V_KLAUNCH(layernorm_kernel<CH>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, \
+                rows, cols, ld_in, ld_out, eps)
+    if (cols <= 4 * 512)
+        O3V_LN(4);
+    else if (cols <= 8 * 512)
+        O3V_LN(8);
+    else
+        O3V_LN(16);
+#undef O3V_LN
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ViT 2-D RoPE in place on the q and k thirds of qkv [P, 3*H*D] (TF:160-171): fp32,
 // q*cos + rotate_half(q)*sin with separately rounded products, one cast back to bf16.
 // cos/sin: fp32 [P, D/2] (the table is cat(rot, rot), so column d and d+D/2 share an entry).
@@ -175,12 +258,16 @@ extern "C" int o3v_mrope_table(const int* pos, const float* inv_freq, const int*
 // b*cs_stride_row + cs_off + (t % tokens_per_row)  (prefill: the [B*S,D] table; decode: step `cs_off`
 // of the per-sequence [B,Tnew,D] table).
 // ------------------------------------------------------------------------------------------------
+// QKNORM (Qwen3-VL, TF3:480-481): q and k heads go through RMSNorm over head_dim (weights q_norm / k_norm) before the
+// rotation; the D/16 lanes that hold one head are neighbours, so the sum of squares is a few lane exchanges.
+template <bool QKNORM>
 __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cosT,
                                                              const bf16_t* __restrict__ sinT, bf16_t* __restrict__ qout,
                                                              bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                              int slot_base, int T, int tokens_per_row,
                                                              int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
-                                                             int cs_off) {
+                                                             int cs_off, const bf16_t* __restrict__ q_norm,
+                                                             const bf16_t* __restrict__ k_norm, float eps) {
     const int half = D >> 1, cpr = half >> 3;
     const int HT = Hq + 2 * Hkv;
     const long total = (long)T * HT * cpr;
@@ -195,6 +282,35 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(const bf16_t* __res
         const bf16_t* src = qkv + (size_t)t * HT * D + (size_t)h * D + c * 8;
         uint4 lo = *reinterpret_cast<const uint4*>(src);
         uint4 hi = *reinterpret_cast<const uint4*>(src + half);
+        if (QKNORM) {
+            // every lane of the head's group takes part (v heads too: their sum is simply not used)
+            const uint32_t* xl = reinterpret_cast<const uint32_t*>(&lo);
+            const uint32_t* xh = reinterpret_cast<const uint32_t*>(&hi);
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ss = fmaf(bf_lo(xl[j]), bf_lo(xl[j]), ss);
+                ss = fmaf(bf_hi(xl[j]), bf_hi(xl[j]), ss);
+                ss = fmaf(bf_lo(xh[j]), bf_lo(xh[j]), ss);
+                ss = fmaf(bf_hi(xh[j]), bf_hi(xh[j]), ss);
+            }
+            for (int m = 1; m < cpr; m <<= 1) ss += __shfl_xor(ss, m, 64);
+            if (h < Hq + Hkv) {
+                const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+                const bf16_t* nw = (h < Hq ? q_norm : k_norm) + c * 8;
+                const uint4 wl = *reinterpret_cast<const uint4*>(nw);
+                const uint4 wh = *reinterpret_cast<const uint4*>(nw + half);
+                const uint32_t* pwl = reinterpret_cast<const uint32_t*>(&wl);
+                const uint32_t* pwh = reinterpret_cast<const uint32_t*>(&wh);
+                uint32_t* yl = reinterpret_cast<uint32_t*>(&lo);
+                uint32_t* yh = reinterpret_cast<uint32_t*>(&hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    yl[j] = pack_bf2(bf_lo(pwl[j]) * rbf(bf_lo(xl[j]) * rstd), bf_hi(pwl[j]) * rbf(bf_hi(xl[j]) * rstd));
+                    yh[j] = pack_bf2(bf_lo(pwh[j]) * rbf(bf_lo(xh[j]) * rstd), bf_hi(pwh[j]) * rbf(bf_hi(xh[j]) * rstd));
+                }
+            }
+        }
         bf16_t* dst;
         if (h < Hq) {
             dst = qout + ((size_t)t * Hq + h) * D + c * 8;
@@ -243,9 +359,61 @@ extern "C" int o3v_qkv_rope_cache(const void* qkv, const void* cosT, const void*
     long total = (long)T * (Hq + 2 * Hkv) * (D >> 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    O3V_KLAUNCH(qkv_rope_cache_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
+    O3V_KLAUNCH(qkv_rope_cache_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
                        (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache, slot_base, T, tokens_per_row, Hq,
-                       Hkv, D, Tmax, cs_stride_row, cs_off);
+                       Hkv, D, Tmax, cs_stride_row, cs_off, (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0.f);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+extern "C" int o3v_qkv_norm_rope_cache(const void* qkv, const void* q_norm, const void* k_norm, float eps, const void* cosT,
+                                       const void* sinT, void* qout, void* kcache, void* vcache, int slot_base, int T,
+                                       int tokens_per_row, int Hq, int Hkv, int D, int Tmax, int cs_stride_row, int cs_off,
+                                       hipStream_t stream) {
+    if (!qkv || !q_norm || !k_norm || !cosT || !sinT || !qout || !kcache || !vcache || T < 0 || tokens_per_row <= 0 || Hq <= 0 ||
+        Hkv <= 0 || D <= 0 || (D & 15))
+        return O3V_ERR_ARG;
+    const int cpr = D >> 4;
+    if (cpr & (cpr - 1) || cpr > 64) return O3V_ERR_SHAPE;  // the head's lanes exchange by xor: a power of two of them
+    if (T == 0) return O3V_OK;
+    long total = (long)T * (Hq + 2 * Hkv) * cpr;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    O3V_KLAUNCH(qkv_rope_cache_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)cosT,
+                       (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache, slot_base, T, tokens_per_row, Hq,
+                       Hkv, D, Tmax, cs_stride_row, cs_off, (const bf16_t*)q_norm, (const bf16_t*)k_norm, eps);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DeepStack (Qwen3-VL, TF3:839-862): x[rows[i], :] = bf16(x[rows[i], :] + feat[src[i], :]) after the first decoder layers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ x, const int* __restrict__ rows,
+                                                       const int* __restrict__ src, const bf16_t* __restrict__ feat, int n,
+                                                       int chunks) {
+    const long total = (long)n * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks), r = (int)(i / chunks);
+        uint4* xp = reinterpret_cast<uint4*>(x + ((size_t)rows[r] * chunks + c) * 8);
+        const uint4 a = *xp, b = *reinterpret_cast<const uint4*>(feat + ((size_t)src[r] * chunks + c) * 8);
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+        uint4 o;
+        uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[j] = pack_bf2(bf_lo(pa[j]) + bf_lo(pb[j]), bf_hi(pa[j]) + bf_hi(pb[j]));
+        *xp = o;
+    }
+}
+
+extern "C" int o3v_add_rows(void* x, const int* rows, const int* src, const void* feat, int n, int hidden, hipStream_t stream) {
+    if (!x || !rows || !src || !feat || n < 0 || hidden <= 0 || (hidden & 7)) return O3V_ERR_ARG;
+    if (n == 0) return O3V_OK;
+    long total = (long)n * (hidden >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    O3V_KLAUNCH(add_rows_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)x, rows, src, (const bf16_t*)feat, n, hidden >> 3);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }
@@ -348,9 +516,9 @@ extern "C" int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0,
 // ------------------------------------------------------------------------------------------------
 template <typename TIN>
 __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ frames, bf16_t* __restrict__ dst, int T,
-                                                       int H, int W, int Kp, float m0, float m1, float m2, float s0,
+                                                       int H, int W, int Kp, int PS, float m0, float m1, float m2, float s0,
                                                        float s1, float s2) {
-    const int PS = 14, gh = H / PS, gw = W / PS, ppf = gh * gw, gwm = gw >> 1;
+    const int gh = H / PS, gw = W / PS, ppf = gh * gw, gwm = gw >> 1;
     const int cpr = Kp >> 3;
     const long total = (long)T * ppf * cpr;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -387,22 +555,28 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ f
     }
 }
 
-extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
-                            const float* std3, hipStream_t stream) {
-    if (!frames || !dst || !mean3 || !std3 || T < 0 || H <= 0 || W <= 0 || (H % 28) || (W % 28) || Kp < 1176 || (Kp & 7))
+extern "C" int o3v_patchify_ps(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, int patch,
+                               const float* mean3, const float* std3, hipStream_t stream) {
+    if (!frames || !dst || !mean3 || !std3 || T < 0 || H <= 0 || W <= 0 || patch <= 0 || (H % (2 * patch)) || (W % (2 * patch)) ||
+        Kp < 6 * patch * patch || (Kp & 7))
         return O3V_ERR_ARG;
     if (T == 0) return O3V_OK;
-    long total = (long)T * (H / 14) * (W / 14) * (Kp >> 3);
+    long total = (long)T * (H / patch) * (W / patch) * (Kp >> 3);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (is_u8)
         O3V_KLAUNCH(patchify_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
-                           T, H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+                           T, H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     else
         O3V_KLAUNCH(patchify_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
-                           H, W, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+                           H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, const float* mean3,
+                            const float* std3, hipStream_t stream) {
+    return o3v_patchify_ps(frames, is_u8, dst, T, H, W, Kp, 14, mean3, std3, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

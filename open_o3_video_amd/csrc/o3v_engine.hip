@@ -50,7 +50,7 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
-extern "C" int o3v_abi_version(void) { return 4; }
+extern "C" int o3v_abi_version(void) { return 5; }
 
 // ------------------------------------------------------------------------------------------------ ViT
 extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
@@ -116,6 +116,94 @@ extern "C" int o3v_vit_forward(const o3v_vit_desc* d, const void* pixels, int P,
     return O3V_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ ViT, Qwen3-VL
+// TF3 = transformers 5.15.0 models/qwen3_vl/modeling_qwen3_vl.py.  Differences from the Qwen2.5-VL tower: patch-embed bias and
+// a learned position table (interpolated per grid on the host side, added in the patch GEMM's epilogue), LayerNorm with bias,
+// plain fc1 -> GELU(tanh) -> fc2 MLP, full attention inside every temporal patch (no windows, no row permutation), and
+// DeepStack: after the blocks in deep_index[] a second kind of merger (LayerNorm over the 4-patch group) taps the stream.
+// Heads of 72 dims are stored 80 wide ([36 | 4 zeros | 36 | 4 zeros], weights packed on the host), which keeps the rotary
+// halves aligned and reuses the 80-wide attention tiles; the softmax scale stays 72^-1/2.
+namespace {
+inline int pad64(int n) { return (n + 63) & ~63; }
+}
+
+extern "C" size_t o3v_vit3_workspace_bytes(const o3v_vit3_desc* d, int P) {
+    if (!d || P <= 0 || d->merge_unit <= 0) return 0;
+    const size_t hid = d->hidden, hp = pad64(d->hidden), W = (size_t)d->heads * d->head_dim_pad;
+    const size_t Pm = (size_t)P / d->merge_unit, mh = hid * d->merge_unit;
+    size_t n = 0;
+    n += align256((size_t)P * hid * 2);          // x
+    n += align256((size_t)P * hp * 2);           // h (K-padded LayerNorm output)
+    n += align256((size_t)P * 3 * W * 2);        // qkv
+    n += align256((size_t)P * W * 2);            // att
+    n += align256((size_t)P * d->inter_pad * 2); // mlp
+    n += align256(Pm * mh * 2);                  // m0
+    n += align256(Pm * mh * 2);                  // m1
+    return n;
+}
+
+namespace {
+int vit3_merger(const o3v_vit3_merger_w& m, const char* x, char* m0, char* m1, void* out, int P, int hid, int unit, int out_hidden,
+                int tile, o3v_stream_t s) {
+    const int Pm = P / unit, mh = hid * unit;
+    if (m.postshuffle)
+        TRY(o3v_layernorm(x, m.norm_w, m.norm_b, m0, Pm, mh, mh, mh, 1e-6f, s));
+    else
+        TRY(o3v_layernorm(x, m.norm_w, m.norm_b, m0, P, hid, hid, hid, 1e-6f, s));
+    TRY(o3v_gemm_bf16_tile(m0, m.fc1_w, m.fc1_b, nullptr, m1, Pm, mh, mh, mh, mh, mh, 0, O3V_EPI_GELU, tile, s));
+    TRY(o3v_gemm_bf16_tile(m1, m.fc2_w, m.fc2_b, nullptr, out, Pm, out_hidden, mh, mh, mh, out_hidden, 0, O3V_EPI_NONE, tile, s));
+    return O3V_OK;
+}
+}  // namespace
+
+extern "C" int o3v_vit3_forward(const o3v_vit3_desc* d, const void* pixels, int P, const void* pos_embed, const float* cosT,
+                                const float* sinT, const int* tiles, int n_tiles, void* workspace, size_t ws_bytes, void* out,
+                                void* deep_out, o3v_stream_t s) {
+    if (!d || !pixels || !pos_embed || !cosT || !sinT || !tiles || !workspace || !out) return O3V_ERR_ARG;
+    if (P <= 0 || d->merge_unit <= 0 || (P % d->merge_unit) || d->heads <= 0 || d->n_deep < 0 || d->n_deep > O3V_MAX_DEEPSTACK ||
+        (d->n_deep && !deep_out))
+        return O3V_ERR_ARG;
+    const int hid = d->hidden, hp = pad64(hid), H = d->heads, Dp = d->head_dim_pad, W = H * Dp, unit = d->merge_unit,
+              Pm = P / unit, ip = d->inter_pad;
+    if ((W % 64) || (ip % 64) || ((hid * unit) % 64) || (hid & 7)) return O3V_ERR_SHAPE;
+    if (ws_bytes < o3v_vit3_workspace_bytes(d, P)) return O3V_ERR_WORKSPACE;
+    Carver cv{(char*)workspace, 0, ws_bytes};
+    char* x = (char*)cv.take((size_t)P * hid * 2);
+    char* h = (char*)cv.take((size_t)P * hp * 2);
+    char* qkv = (char*)cv.take((size_t)P * 3 * W * 2);
+    char* att = (char*)cv.take((size_t)P * W * 2);
+    char* mlp = (char*)cv.take((size_t)P * ip * 2);
+    char* m0 = (char*)cv.take((size_t)Pm * hid * unit * 2);
+    char* m1 = (char*)cv.take((size_t)Pm * hid * unit * 2);
+    if (!m1) return O3V_ERR_WORKSPACE;
+    const float scale = 1.0f / sqrtf((float)d->head_dim);
+    if (hp != hid && hipMemsetAsync(h, 0, (size_t)P * hp * 2, (hipStream_t)s) != hipSuccess) return O3V_ERR_LAUNCH;
+
+    // patch embed: Conv3d(k = s) == GEMM, + bias, + interpolated position rows (TF3:606-640, :700-710)
+    TRY(o3v_gemm_bf16_tile(pixels, d->patch_w, d->patch_b, pos_embed, x, P, hid, d->patch_k_pad, d->patch_k_pad, d->patch_k_pad, hid,
+                           hid, O3V_EPI_RESIDUAL, d->gemm_tile, s));
+    int next_deep = 0;
+    for (int i = 0; i < d->depth; ++i) {
+        const o3v_vit3_block_w& w = d->blocks[i];
+        TRY(o3v_layernorm(x, w.norm1_w, w.norm1_b, h, P, hid, hid, hp, 1e-6f, s));
+        TRY(o3v_gemm_bf16_tile(h, w.qkv_w, w.qkv_b, nullptr, qkv, P, 3 * W, hp, hp, hp, 3 * W, 0, O3V_EPI_NONE, d->gemm_tile, s));
+        TRY(o3v_vit_rope(qkv, cosT, sinT, P, H, Dp, s));
+        TRY(o3v_attn_tiles(qkv, qkv + (size_t)W * 2, qkv + (size_t)2 * W * 2, att, tiles, n_tiles, 64, H, 1, Dp, 3L * W, 3L * W, Dp, 0,
+                           3L * W, Dp, 0, W, scale, s));
+        TRY(o3v_gemm_bf16_tile(att, w.proj_w, w.proj_b, x, x, P, hid, W, W, W, hid, hid, O3V_EPI_RESIDUAL, d->gemm_tile, s));
+        TRY(o3v_layernorm(x, w.norm2_w, w.norm2_b, h, P, hid, hid, hp, 1e-6f, s));
+        TRY(o3v_gemm_bf16_tile(h, w.fc1_w, w.fc1_b, nullptr, mlp, P, ip, hp, hp, hp, ip, 0, O3V_EPI_GELU_TANH, d->gemm_tile, s));
+        TRY(o3v_gemm_bf16_tile(mlp, w.fc2_w, w.fc2_b, x, x, P, hid, ip, ip, ip, hid, hid, O3V_EPI_RESIDUAL, d->gemm_tile, s));
+        if (next_deep < d->n_deep && d->deep_index[next_deep] == i) {
+            TRY(vit3_merger(d->deep[next_deep], x, m0, m1, (char*)deep_out + (size_t)next_deep * Pm * d->out_hidden * 2, P, hid, unit,
+                            d->out_hidden, d->gemm_tile, s));
+            ++next_deep;
+        }
+    }
+    if (next_deep != d->n_deep) return O3V_ERR_ARG;  // deep_index must be ascending and < depth
+    return vit3_merger(d->merger, x, m0, m1, out, P, hid, unit, d->out_hidden, d->gemm_tile, s);
+}
+
 // ------------------------------------------------------------------------------------------------ LLM
 namespace {
 // fp32 partials of the widest split-K linear (q/k/v or hidden outputs; gate/up has enough tiles on its own)
@@ -171,7 +259,18 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
 extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
                                int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int past,
                                int Tmax, void* workspace, size_t ws_bytes, o3v_stream_t s) {
+    return o3v_llm_prefill_deepstack(d, x, cosT, sinT, tiles, n_tiles, rows_per_tile, kcache, vcache, B, S, past, Tmax, nullptr,
+                                     nullptr, 0, nullptr, 0, 0, workspace, ws_bytes, s);
+}
+
+// ds_*: DeepStack (TF3:839-862).  After decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]] for the n_ds visual
+// rows of this call; ds_feat holds n_deep tables of ds_stride elements each.
+extern "C" int o3v_llm_prefill_deepstack(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
+                                         int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int past,
+                                         int Tmax, const int* ds_rows, const int* ds_src, int n_ds, const void* ds_feat,
+                                         int n_deep, long ds_stride, void* workspace, size_t ws_bytes, o3v_stream_t s) {
     if (!d || !x || !cosT || !sinT || !tiles || !kcache || !vcache || !workspace) return O3V_ERR_ARG;
+    if (n_ds < 0 || n_deep < 0 || (n_ds > 0 && n_deep > 0 && (!ds_rows || !ds_src || !ds_feat))) return O3V_ERR_ARG;
     if (B <= 0 || S <= 0 || past < 0 || past + S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
     const int rows = B * S, H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter;
     const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
@@ -185,13 +284,19 @@ extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT,
         char* vc = (char*)vcache + l * layer_stride;
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes, d->gemm_tile));
-        TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
+        if (lw.q_norm)
+            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax,
+                                        S, 0, s));
+        else
+            TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
         TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
                            (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
         TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s, nullptr, 0, d->gemm_tile));
         TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
+        if (l < n_deep && n_ds > 0)
+            TRY(o3v_add_rows(x, ds_rows, ds_src, (const char*)ds_feat + (size_t)l * ds_stride * 2, n_ds, H, s));
     }
     return O3V_OK;
 }
@@ -246,14 +351,24 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
     // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
     const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
-    bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
+    const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
+    bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0 && !qk_norm;
     int step = step0;
     // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
     auto attention_half = [&](int l) -> int {
         const o3v_llm_layer_w& lw = d->layer[l];
         char* kc = (char*)st->kcache + l * layer_stride;
         char* vc = (char*)st->vcache + l * layer_stride;
-        if (fp8) {
+        if (qk_norm) {
+            if (fp8)
+                TRY(o3v_linear_decode_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
+                                          O3V_EPI_NONE, s));
+            else
+                TRY(o3v_linear_decode(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
+                                      O3V_EPI_NONE, s));
+            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, st->cosT, st->sinT, w.q, kc, vc, st->S + step, B, 1, Hq,
+                                        Hkv, D, st->Tmax, st->Tnew, step, s));
+        } else if (fp8) {
             TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
                                            kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         } else if (norm_apart) {

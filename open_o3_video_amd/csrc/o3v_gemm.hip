@@ -125,6 +125,10 @@ __device__ __forceinline__ void wave_epilogue(const f32x4 (&acc)[4][4], float* e
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = gelu_erf_f(rbf(v[q]));
                 }
+                if (EPI == EPI_GELU_TANH) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_tanh_f(rbf(v[q]));
+                }
                 u32x4 pk;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pk[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
@@ -171,6 +175,7 @@ __device__ __forceinline__ void wave_epilogue(const f32x4 (&acc)[4][4], float* e
                     float v = acc[i][j][r] + bv;
                     if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
                     if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+            if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
                     out[(size_t)m * ldo + n] = f2bf(v);
                 }
             }
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
             float v = acc[0][r] + e_bias[0][r];
             if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[r];
             if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+            if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
             out[(size_t)m * ldo + n] = f2bf(v);
         }
     }
@@ -739,6 +745,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (bias) v += bf2f(bias[n]);
         if (EPI == EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldr + n]);
         if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+            if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
         out[(size_t)m * ldo + n] = f2bf(v);
     }
 }
@@ -805,6 +812,7 @@ extern "C" int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias
             case EPI_NONE: O3V_GM2(EPI_NONE); break;
             case EPI_RESIDUAL: O3V_GM2(EPI_RESIDUAL); break;
             case EPI_GELU: O3V_GM2(EPI_GELU); break;
+            case EPI_GELU_TANH: O3V_GM2(EPI_GELU_TANH); break;
             case EPI_SWIGLU: O3V_GM2(EPI_SWIGLU); break;
             default: return O3V_ERR_ARG;
         }
@@ -821,6 +829,7 @@ extern "C" int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias
         case EPI_NONE: O3V_GM(EPI_NONE); break;
         case EPI_RESIDUAL: O3V_GM(EPI_RESIDUAL); break;
         case EPI_GELU: O3V_GM(EPI_GELU); break;
+        case EPI_GELU_TANH: O3V_GM(EPI_GELU_TANH); break;
         case EPI_SWIGLU: O3V_GM(EPI_SWIGLU); break;
         default: return O3V_ERR_ARG;
     }

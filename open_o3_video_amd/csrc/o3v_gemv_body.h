@@ -8,6 +8,7 @@
 #define EPI_RESIDUAL 1
 #define EPI_GELU 2
 #define EPI_SWIGLU 3
+#define EPI_GELU_TANH 6  // Qwen3-VL vision MLP: gelu_pytorch_tanh
 #define EPI_PARTIAL 5  // split-K pass of the MFMA GEMM: raw fp32 tile to the workspace, epilogue in the reduce kernel
 #define EPI_QKVROPE 4  // decode only: bias, M-RoPE, write q / append k,v to the cache (TF:557-599, :652-664)
 
@@ -389,6 +390,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 float v = acc[r][m] + bv;
                 if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[EPI == EPI_RESIDUAL ? r : 0][EPI == EPI_RESIDUAL ? m : 0];
                 if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+            if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
                 gemv_store_bf16<PUB>(out + (size_t)m * ldo + n, f2bf(v));
             }
         }

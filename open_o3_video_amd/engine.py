@@ -56,9 +56,13 @@ class O3VEngine:
         # inv_freq exactly as torch computes it on the host (TF:521)
         inv = 1.0 / (tc.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float) / D))
         self.inv_freq = inv.to(self.dev)
-        self.axis_of = torch.from_numpy(indexing.mrope_axis_table(tc.mrope_section)).to(self.dev)
-        self.clip_mean = (C.c_float * 3)(*CLIP_MEAN)   # host arrays (read by the launcher, passed by value)
-        self.clip_std = (C.c_float * 3)(*CLIP_STD)
+        self.q3 = cfg.arch == "qwen3_vl"
+        axis = indexing.mrope_axis_table_interleaved(tc.mrope_section, D // 2) if tc.mrope_interleaved \
+            else indexing.mrope_axis_table(tc.mrope_section)
+        self.axis_of = torch.from_numpy(axis).to(self.dev)
+        # host arrays (read by the launcher, passed by value); Qwen3-VL's processor normalises with mean = std = 0.5
+        self.clip_mean = (C.c_float * 3)(*((0.5, 0.5, 0.5) if self.q3 else CLIP_MEAN))
+        self.clip_std = (C.c_float * 3)(*((0.5, 0.5, 0.5) if self.q3 else CLIP_STD))
         self._vit_plan_cache = {}
         self._prefix = {}   # prefix_key -> {"ids", "k", "v"}: prompt K/V kept for reuse (see generate(prefix_key=...))
         import os
@@ -73,6 +77,8 @@ class O3VEngine:
         if p is not None:
             return p
         vc = self.cfg.vision
+        if self.q3:
+            return self._vit_plan_q3(key)
         widx, cu_win, cu_full, pos = indexing.vision_plan(key, vc.spatial_merge_size, vc.window_size, vc.patch_size)
         unit = vc.merge_unit
         P = int(cu_full[-1])
@@ -95,6 +101,32 @@ class O3VEngine:
         self._vit_plan_cache[key] = plan
         return plan
 
+    def _vit_plan_q3(self, key):
+        """Qwen3-VL (TF3:606-737): no windows -- patches stay in merge-block order, one attention segment per temporal patch;
+        the rotary table is stored head_dim_pad/2 wide (the padded frequencies rotate zeros); the learned position table is
+        resampled to this grid once (TF3:643-710: four taps, table dtype x fp32 weights, summed in fp32 in tap order)."""
+        vc = self.cfg.vision
+        _, _, cu_full, pos = indexing.vision_plan(key, vc.spatial_merge_size, vc.patch_size * vc.spatial_merge_size, vc.patch_size)
+        P = int(cu_full[-1])
+        rdim = vc.head_dim // 2
+        inv = 1.0 / (10000.0 ** (torch.arange(0, rdim, 2, dtype=torch.float) / rdim))
+        rot = (torch.from_numpy(pos).unsqueeze(-1) * inv).flatten(1)            # [P, hd/2]
+        halfp = vc.head_dim_pad // 2
+        cos, sin = torch.ones((P, halfp)), torch.zeros((P, halfp))
+        cos[:, :rot.shape[1]], sin[:, :rot.shape[1]] = rot.cos(), rot.sin()
+        side = int(round(vc.num_position_embeddings ** 0.5))
+        idx, wt = indexing.pos_embed_taps(key, side, vc.spatial_merge_size)
+        table = self.w.t["v.pos_embed"]
+        idx, wt = torch.from_numpy(idx).to(self.dev), torch.from_numpy(wt).to(self.dev)
+        taps = [table[idx[:, k]] * wt[:, k, None] for k in range(4)]           # bf16 x fp32 -> fp32
+        pe = (((taps[0] + taps[1]) + taps[2]) + taps[3]).to(torch.bfloat16).contiguous()
+        plan = dict(P=P, cos=cos.contiguous().to(self.dev), sin=sin.contiguous().to(self.dev), pos_embed=pe,
+                    tiles_full=torch.from_numpy(indexing.segment_tiles(cu_full)).to(self.dev))
+        if len(self._vit_plan_cache) > 16:
+            self._vit_plan_cache.clear()
+        self._vit_plan_cache[key] = plan
+        return plan
+
     def pixels_from_processor(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """HF-processor pixel_values f32 [P,1176] -> bf16 [P,Kp] (TF:1090 cast, zero pad)."""
         vc = self.cfg.vision
@@ -109,14 +141,16 @@ class O3VEngine:
         if frames.dim() != 4 or frames.shape[1] != 3:
             raise ValueError("frames must be [T,3,H,W]")
         T, _, H, W = frames.shape
-        if H % 28 or W % 28:
-            raise ValueError("frame size must be a multiple of 28 (smart_resize output)")
+        ps = vc.patch_size
+        if H % (2 * ps) or W % (2 * ps):
+            raise ValueError(f"frame size must be a multiple of {2 * ps} (smart_resize output)")
         is_u8 = frames.dtype == torch.uint8
         fr = frames.to(self.dev).contiguous() if is_u8 else frames.to(self.dev, torch.float32).contiguous()
-        P = T * (H // 14) * (W // 14)
+        P = T * (H // ps) * (W // ps)
         out = torch.empty((P, vc.patch_k_pad), dtype=torch.bfloat16, device=self.dev)
-        _lib.call("o3v_patchify", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, self.clip_mean, self.clip_std, _stream())
-        grid = np.asarray([[1, H // 14, W // 14]] * T, dtype=np.int64)
+        _lib.call("o3v_patchify_ps", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, ps, self.clip_mean, self.clip_std,
+                  _stream())
+        grid = np.asarray([[1, H // ps, W // ps]] * T, dtype=np.int64)
         return out, grid
 
     def vit_forward(self, pixels_bf16: torch.Tensor, grid_thw) -> torch.Tensor:
@@ -126,6 +160,17 @@ class O3VEngine:
         P = plan["P"]
         if pixels_bf16.shape[0] != P or pixels_bf16.shape[1] != vc.patch_k_pad:
             raise ValueError(f"pixel rows {tuple(pixels_bf16.shape)} do not match grid ({P} patches)")
+        if self.q3:
+            # [1 + n_deep, P/4, out_hidden]: row block 0 = the merged visual tokens, 1.. = the DeepStack features (TF3:839-862) that
+            # prefill adds to the first decoder layers' outputs at the visual positions; every consumer takes this one tensor
+            nd = len(vc.deepstack_visual_indexes)
+            nbytes = _lib.load().o3v_vit3_workspace_bytes(C.byref(self.w.vit3), P)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            out = torch.empty((1 + nd, P // vc.merge_unit, vc.out_hidden_size), dtype=torch.bfloat16, device=self.dev)
+            _lib.call("o3v_vit3_forward", C.byref(self.w.vit3), _ptr(pixels_bf16), P, _ptr(plan["pos_embed"]), _ptr(plan["cos"]),
+                      _ptr(plan["sin"]), _ptr(plan["tiles_full"]), plan["tiles_full"].shape[0], _ptr(ws), nbytes, _ptr(out[0]),
+                      _ptr(out[1:]) if nd else None, _stream())
+            return out
         nbytes = _lib.load().o3v_vit_workspace_bytes(C.byref(self.w.vit), P)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         out = torch.empty((P // vc.merge_unit, vc.out_hidden_size), dtype=torch.bfloat16, device=self.dev)
@@ -148,6 +193,8 @@ class O3VEngine:
     def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor], first: int = 0) -> torch.Tensor:
         """inputs_embeds of the (flattened) prompt; `first` > 0 returns only rows first.. (prefix-KV reuse)."""
         src, n_img = indexing.embed_source_rows(input_ids, self.cfg.image_token_id)
+        if vis is not None and vis.dim() == 3:      # Qwen3-VL: [1 + n_deep, n, H], block 0 = the visual tokens
+            vis = vis[0]
         if n_img and (vis is None or vis.shape[0] != n_img):
             raise ValueError(f"Image features and image tokens do not match, tokens: {n_img}, "
                              f"features: {0 if vis is None else vis.shape[0]}")
@@ -165,11 +212,26 @@ class O3VEngine:
         return (torch.empty(shape, dtype=torch.bfloat16, device=self.dev),
                 torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
 
-    def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc, past: int = 0):
+    def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc, past: int = 0,
+                deepstack=None):
         """Runs the prompt through the LLM (TF:790-872); x [B*S,H] becomes the last layer's residual stream.
         past > 0: slots 0..past-1 of the caches already hold a prompt prefix (HF `past_key_values` semantics);
-        x / pos3 are the S tokens after it."""
+        x / pos3 are the S tokens after it.  deepstack = (input_ids, vis [1+n_deep, n, H]) of a Qwen3-VL prompt: the DeepStack
+        features are added after the first decoder layers at the visual rows (TF3:839-862)."""
         Tmax = kc.shape[3]
+        if deepstack is not None and deepstack[1] is not None and deepstack[1].dim() == 3 and deepstack[1].shape[0] > 1:
+            ids_all, vis = deepstack
+            rows, src = indexing.deepstack_rows(ids_all, self.cfg.image_token_id, first=past)
+            cos, sin = self.mrope_table(pos3.reshape(3, B * S))
+            tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad, past=past)).to(self.dev)
+            nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            rows_d, src_d = torch.from_numpy(rows).to(self.dev), torch.from_numpy(src).to(self.dev)
+            feat = vis[1:]
+            _lib.call("o3v_llm_prefill_deepstack", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
+                      indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, int(past), Tmax, _ptr(rows_d), _ptr(src_d), int(rows.shape[0]),
+                      _ptr(feat), int(feat.shape[0]), int(feat.stride(0)), _ptr(ws), nbytes, _stream())
+            return x
         cos, sin = self.mrope_table(pos3.reshape(3, B * S))
         tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad, past=past)).to(self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
@@ -254,15 +316,16 @@ class O3VEngine:
         if use_prefix:
             past = self._prefix_lookup(prefix_key, ids[0])
         x = self.embed(ids, vis, first=past)
+        ds = (ids, vis) if self.q3 else None
         if G == 1 and not use_prefix:
-            self.prefill(x, pos, pad, B0, S, kc, vc)
+            self.prefill(x, pos, pad, B0, S, kc, vc, deepstack=ds)
         else:
             kc0, vc0 = self.alloc_cache(B0, S)
             if past:
                 ent = self._prefix[prefix_key]
                 kc0[:, :, :, :past].copy_(ent["k"][:, :, :, :past])
                 vc0[:, :, :, :past].copy_(ent["v"][:, :, :, :past])
-            self.prefill(x, pos[:, :, past:], pad, B0, S - past, kc0, vc0, past=past)
+            self.prefill(x, pos[:, :, past:], pad, B0, S - past, kc0, vc0, past=past, deepstack=ds)
             # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
             # (a broadcast copy into the [layers, B0, G, ...] view of the caches: no G-times temporary)
             shp = (kc.shape[0], B0, G) + tuple(kc.shape[2:])
@@ -438,7 +501,7 @@ class O3VEngine:
             pos = np.broadcast_to(p1[None], (3, B, S)).copy()
         kc, vc = self.alloc_cache(B, S)
         x = self.embed(ids, vis)
-        self.prefill(x, pos, pad, B, S, kc, vc)
+        self.prefill(x, pos, pad, B, S, kc, vc, deepstack=(ids, vis) if self.q3 else None)
         return self.head(x).view(B, S, -1)
 
     @torch.no_grad()
@@ -485,7 +548,7 @@ class O3VEngine:
         # prompt once
         kc0, vc0 = self.alloc_cache(1, S)
         x = self.embed(ids, vis)
-        self.prefill(x, pos, pad, 1, S, kc0, vc0)
+        self.prefill(x, pos, pad, 1, S, kc0, vc0, deepstack=(ids, vis) if self.q3 else None)
         x_last = x[S - 1:S].clone()                               # hidden state that predicts completion token 0
         del x
         rows = torch.empty((G, T, H), dtype=torch.bfloat16, device=self.dev)

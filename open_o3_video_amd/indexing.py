@@ -159,3 +159,58 @@ def mrope_axis_table(mrope_section):
     for i, n in enumerate(mrope_section):
         ax += [i % 3] * int(n)
     return np.asarray(ax, dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------ Qwen3-VL
+def mrope_axis_table_interleaved(mrope_section, half):
+    """Interleaved M-RoPE (Qwen3-VL, TF3:368-390): rotary frequency j takes the H axis when j % 3 == 1 and j < 3*section[1], the
+    W axis when j % 3 == 2 and j < 3*section[2], the T axis otherwise."""
+    j = np.arange(int(half))
+    ax = np.zeros(int(half), dtype=np.int32)
+    ax[(j % 3 == 1) & (j < 3 * int(mrope_section[1]))] = 1
+    ax[(j % 3 == 2) & (j < 3 * int(mrope_section[2]))] = 2
+    return ax
+
+
+def _interp_axis(n, side):
+    # TF:vision_utils._interpolation_axis_taps_weights (bilinear, align_corners=True), the same float32 operation order
+    i = np.arange(n, dtype=np.float32)
+    src = i * np.float32(side - 1) / np.float32(max(n - 1, 1))
+    fl = np.floor(src)
+    lo = np.clip(fl.astype(np.int64), 0, side - 1)
+    hi = np.clip(fl.astype(np.int64) + 1, 0, side - 1)
+    w_lo = np.maximum(np.float32(1) - np.abs(src - fl), np.float32(0))
+    w_hi = np.maximum(np.float32(1) - np.abs(src - fl - np.float32(1)), np.float32(0))
+    return lo, hi, w_lo.astype(np.float32), w_hi.astype(np.float32)
+
+
+@lru_cache(maxsize=64)
+def _pos_embed_taps_cached(key, side, merge):
+    idx_all, w_all = [], []
+    for (t, h, w) in key:
+        rlo, rhi, rwl, rwh = _interp_axis(h, side)
+        clo, chi, cwl, cwh = _interp_axis(w, side)
+        bh, bw, ih, iw = np.meshgrid(np.arange(h // merge), np.arange(w // merge), np.arange(merge), np.arange(merge), indexing="ij")
+        rows = (bh * merge + ih).reshape(-1)
+        cols = (bw * merge + iw).reshape(-1)
+        idx = np.stack([rlo[rows] * side + clo[cols], rlo[rows] * side + chi[cols],
+                        rhi[rows] * side + clo[cols], rhi[rows] * side + chi[cols]], axis=1)
+        wt = np.stack([rwl[rows] * cwl[cols], rwl[rows] * cwh[cols], rwh[rows] * cwl[cols], rwh[rows] * cwh[cols]], axis=1)
+        idx_all.append(np.tile(idx, (t, 1)))
+        w_all.append(np.tile(wt, (t, 1)))
+    return np.concatenate(idx_all).astype(np.int64), np.concatenate(w_all).astype(np.float32)
+
+
+def pos_embed_taps(grid_thw, side, merge=2):
+    """Qwen3-VL learned position table resampled to each image grid (TF3:643-710): per patch, in merge-block order, the four
+    table rows and bilinear weights -> (idx i64 [P,4], w f32 [P,4])."""
+    return _pos_embed_taps_cached(_grid_key(grid_thw), int(side), int(merge))
+
+
+def deepstack_rows(input_ids, image_token_id, first=0):
+    """Rows of the visual tokens among the flattened prompt rows first.. and their ordinal among all visual tokens."""
+    ids = np.asarray(input_ids).reshape(-1)
+    at = np.flatnonzero(ids == image_token_id)
+    order = np.arange(at.shape[0])
+    keep = at >= first
+    return (at[keep] - first).astype(np.int32), order[keep].astype(np.int32)

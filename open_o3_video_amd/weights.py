@@ -113,38 +113,11 @@ class DeviceWeights:
             return g("model.language_model." + name, "model." + name, "language_model.model." + name)
 
         keep = self.t
-        # ---- vision
-        pw = v("patch_embed.proj.weight").reshape(vc.hidden_size, -1)
-        keep["v.patch_w"] = pad_cols(pw, vc.patch_k_pad)
-        self.vit_blocks = (_lib.VitBlockW * vc.depth)()
-        for i in range(vc.depth):
-            b = f"blocks.{i}."
-            keep[f"v{i}.norm1"] = v(b + "norm1.weight").contiguous()
-            keep[f"v{i}.norm2"] = v(b + "norm2.weight").contiguous()
-            keep[f"v{i}.qkv_w"] = v(b + "attn.qkv.weight").contiguous()
-            keep[f"v{i}.qkv_b"] = v(b + "attn.qkv.bias").contiguous()
-            keep[f"v{i}.proj_w"] = v(b + "attn.proj.weight").contiguous()
-            keep[f"v{i}.proj_b"] = v(b + "attn.proj.bias").contiguous()
-            keep[f"v{i}.gu_w"] = pack_gate_up(v(b + "mlp.gate_proj.weight"), v(b + "mlp.up_proj.weight"), vc.inter_pad)
-            keep[f"v{i}.gu_b"] = pack_gate_up(v(b + "mlp.gate_proj.bias"), v(b + "mlp.up_proj.bias"), vc.inter_pad)
-            keep[f"v{i}.down_w"] = pad_cols(v(b + "mlp.down_proj.weight"), vc.inter_pad)
-            keep[f"v{i}.down_b"] = v(b + "mlp.down_proj.bias").contiguous()
-            for f in ("norm1", "norm2", "qkv_w", "qkv_b", "proj_w", "proj_b", "gu_w", "gu_b", "down_w", "down_b"):
-                setattr(self.vit_blocks[i], f, keep[f"v{i}.{f}"].data_ptr())
-        keep["v.ln_q"] = v("merger.ln_q.weight").contiguous()
-        keep["v.m0_w"] = v("merger.mlp.0.weight").contiguous()
-        keep["v.m0_b"] = v("merger.mlp.0.bias").contiguous()
-        keep["v.m2_w"] = v("merger.mlp.2.weight").contiguous()
-        keep["v.m2_b"] = v("merger.mlp.2.bias").contiguous()
-        mask = 0
-        for i in vc.fullatt_block_indexes:
-            mask |= 1 << int(i)
-        self.vit = _lib.VitDesc(depth=vc.depth, hidden=vc.hidden_size, heads=vc.num_heads, inter_pad=vc.inter_pad,
-                                out_hidden=vc.out_hidden_size, patch_k_pad=vc.patch_k_pad, merge_unit=vc.merge_unit,
-                                fullatt_mask=mask, patch_w=keep["v.patch_w"].data_ptr(), blocks=self.vit_blocks,
-                                ln_q=keep["v.ln_q"].data_ptr(), m0_w=keep["v.m0_w"].data_ptr(),
-                                m0_b=keep["v.m0_b"].data_ptr(), m2_w=keep["v.m2_w"].data_ptr(),
-                                m2_b=keep["v.m2_b"].data_ptr())
+        self.vit = self.vit3 = None
+        if cfg.arch == "qwen3_vl":
+            self._pack_vision_q3(v)
+        else:
+            self._pack_vision(v)
         # ---- text
         keep["l.embed"] = l("embed_tokens.weight").contiguous()
         self.llm_layers = (_lib.LlmLayerW * tc.num_hidden_layers)()
@@ -154,12 +127,19 @@ class DeviceWeights:
             keep[f"l{i}.ln2"] = l(b + "post_attention_layernorm.weight").contiguous()
             keep[f"l{i}.qkv_w"] = torch.cat([l(b + "self_attn.q_proj.weight"), l(b + "self_attn.k_proj.weight"),
                                              l(b + "self_attn.v_proj.weight")], dim=0).contiguous()
-            keep[f"l{i}.qkv_b"] = torch.cat([l(b + "self_attn.q_proj.bias"), l(b + "self_attn.k_proj.bias"),
-                                             l(b + "self_attn.v_proj.bias")], dim=0).contiguous()
+            fields = ["ln1", "ln2", "qkv_w", "o_w", "gu_w", "down_w"]
+            if tc.attention_bias:
+                keep[f"l{i}.qkv_b"] = torch.cat([l(b + "self_attn.q_proj.bias"), l(b + "self_attn.k_proj.bias"),
+                                                 l(b + "self_attn.v_proj.bias")], dim=0).contiguous()
+                fields.append("qkv_b")
+            if tc.qk_norm:
+                keep[f"l{i}.q_norm"] = l(b + "self_attn.q_norm.weight").contiguous()
+                keep[f"l{i}.k_norm"] = l(b + "self_attn.k_norm.weight").contiguous()
+                fields += ["q_norm", "k_norm"]
             keep[f"l{i}.o_w"] = l(b + "self_attn.o_proj.weight").contiguous()
             keep[f"l{i}.gu_w"] = pack_gate_up(l(b + "mlp.gate_proj.weight"), l(b + "mlp.up_proj.weight"), tc.inter_pad)
             keep[f"l{i}.down_w"] = pad_cols(l(b + "mlp.down_proj.weight"), tc.inter_pad)
-            for f in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w"):
+            for f in fields:
                 setattr(self.llm_layers[i], f, keep[f"l{i}.{f}"].data_ptr())
             for f in ("qkv_w", "o_w", "gu_w", "down_w"):
                 w = keep[f"l{i}.{f}"]
@@ -195,11 +175,114 @@ class DeviceWeights:
             self.llm.lm_head8, self.llm.lm_head_s = keep["l.head8"].data_ptr(), keep["l.head8s"].data_ptr()
         self._check_shapes()
 
+    def _pack_vision(self, v):
+        """Qwen2.5-VL tower (TF:408-471)."""
+        keep, vc = self.t, self.cfg.vision
+        pw = v("patch_embed.proj.weight").reshape(vc.hidden_size, -1)
+        keep["v.patch_w"] = pad_cols(pw, vc.patch_k_pad)
+        self.vit_blocks = (_lib.VitBlockW * vc.depth)()
+        for i in range(vc.depth):
+            b = f"blocks.{i}."
+            keep[f"v{i}.norm1"] = v(b + "norm1.weight").contiguous()
+            keep[f"v{i}.norm2"] = v(b + "norm2.weight").contiguous()
+            keep[f"v{i}.qkv_w"] = v(b + "attn.qkv.weight").contiguous()
+            keep[f"v{i}.qkv_b"] = v(b + "attn.qkv.bias").contiguous()
+            keep[f"v{i}.proj_w"] = v(b + "attn.proj.weight").contiguous()
+            keep[f"v{i}.proj_b"] = v(b + "attn.proj.bias").contiguous()
+            keep[f"v{i}.gu_w"] = pack_gate_up(v(b + "mlp.gate_proj.weight"), v(b + "mlp.up_proj.weight"), vc.inter_pad)
+            keep[f"v{i}.gu_b"] = pack_gate_up(v(b + "mlp.gate_proj.bias"), v(b + "mlp.up_proj.bias"), vc.inter_pad)
+            keep[f"v{i}.down_w"] = pad_cols(v(b + "mlp.down_proj.weight"), vc.inter_pad)
+            keep[f"v{i}.down_b"] = v(b + "mlp.down_proj.bias").contiguous()
+            for f in ("norm1", "norm2", "qkv_w", "qkv_b", "proj_w", "proj_b", "gu_w", "gu_b", "down_w", "down_b"):
+                setattr(self.vit_blocks[i], f, keep[f"v{i}.{f}"].data_ptr())
+        keep["v.ln_q"] = v("merger.ln_q.weight").contiguous()
+        keep["v.m0_w"] = v("merger.mlp.0.weight").contiguous()
+        keep["v.m0_b"] = v("merger.mlp.0.bias").contiguous()
+        keep["v.m2_w"] = v("merger.mlp.2.weight").contiguous()
+        keep["v.m2_b"] = v("merger.mlp.2.bias").contiguous()
+        mask = 0
+        for i in vc.fullatt_block_indexes:
+            mask |= 1 << int(i)
+        self.vit = _lib.VitDesc(depth=vc.depth, hidden=vc.hidden_size, heads=vc.num_heads, inter_pad=vc.inter_pad,
+                                out_hidden=vc.out_hidden_size, patch_k_pad=vc.patch_k_pad, merge_unit=vc.merge_unit,
+                                fullatt_mask=mask, patch_w=keep["v.patch_w"].data_ptr(), blocks=self.vit_blocks,
+                                ln_q=keep["v.ln_q"].data_ptr(), m0_w=keep["v.m0_w"].data_ptr(),
+                                m0_b=keep["v.m0_b"].data_ptr(), m2_w=keep["v.m2_w"].data_ptr(),
+                                m2_b=keep["v.m2_b"].data_ptr())
+
+    def _pack_vision_q3(self, v):
+        """Qwen3-VL tower (TF3:606-737): LayerNorm + bias, fc1/fc2 MLP, learned position table, main + DeepStack mergers.
+        Heads of head_dim 72 are stored head_dim_pad = 80 wide, each rotary half followed by its share of zero rows
+        ([36 | 4 zeros | 36 | 4 zeros]): the pairs (j, j + 40) the rotation kernel couples are the model's (j, j + 36), the
+        zero dims add nothing to q.k, and the matching zero columns of proj drop the padded outputs."""
+        keep, vc = self.t, self.cfg.vision
+        hid, heads, hd, Dp, hp, ip = vc.hidden_size, vc.num_heads, vc.head_dim, vc.head_dim_pad, vc.hidden_pad, vc.inter_pad
+        dev = self.device
+        half, halfp = hd // 2, Dp // 2
+        j = torch.arange(Dp, device=dev)
+        inner = torch.where(j < halfp, j, j - halfp)
+        src_in_head = torch.where(j < halfp, inner, inner + half)
+        valid = inner < half
+        src = (torch.arange(heads, device=dev)[:, None] * hd + src_in_head[None, :]).reshape(-1)      # [heads*Dp]
+        valid = valid[None, :].expand(heads, Dp).reshape(-1)
+        src = torch.where(valid, src, torch.zeros_like(src))
+
+        def head_rows(w):      # [heads*hd, ...] -> [heads*Dp, ...]
+            out = w[src]
+            out[~valid] = 0
+            return out
+
+        keep["v.patch_w"] = pad_cols(v("patch_embed.proj.weight").reshape(hid, -1), vc.patch_k_pad)
+        keep["v.patch_b"] = v("patch_embed.proj.bias").contiguous()
+        keep["v.pos_embed"] = v("pos_embed.weight").contiguous()
+        self.vit3_blocks = (_lib.Vit3BlockW * vc.depth)()
+        for i in range(vc.depth):
+            b = f"blocks.{i}."
+            for n in ("norm1", "norm2"):
+                keep[f"v{i}.{n}_w"] = v(b + n + ".weight").contiguous()
+                keep[f"v{i}.{n}_b"] = v(b + n + ".bias").contiguous()
+            qw, qb = v(b + "attn.qkv.weight"), v(b + "attn.qkv.bias")
+            keep[f"v{i}.qkv_w"] = pad_cols(torch.cat([head_rows(t) for t in qw.view(3, hid, hid)], dim=0), hp)
+            keep[f"v{i}.qkv_b"] = torch.cat([head_rows(t) for t in qb.view(3, hid)], dim=0).contiguous()
+            keep[f"v{i}.proj_w"] = head_rows(v(b + "attn.proj.weight").t().contiguous()).t().contiguous()
+            keep[f"v{i}.proj_b"] = v(b + "attn.proj.bias").contiguous()
+            f1 = torch.zeros((ip, hp), dtype=torch.bfloat16, device=dev)
+            f1[: vc.intermediate_size, :hid] = v(b + "mlp.linear_fc1.weight")
+            f1b = torch.zeros(ip, dtype=torch.bfloat16, device=dev)
+            f1b[: vc.intermediate_size] = v(b + "mlp.linear_fc1.bias")
+            keep[f"v{i}.fc1_w"], keep[f"v{i}.fc1_b"] = f1, f1b
+            keep[f"v{i}.fc2_w"] = pad_cols(v(b + "mlp.linear_fc2.weight"), ip)
+            keep[f"v{i}.fc2_b"] = v(b + "mlp.linear_fc2.bias").contiguous()
+            for f in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"):
+                setattr(self.vit3_blocks[i], f, keep[f"v{i}.{f}"].data_ptr())
+
+        def merger(prefix, key, post):
+            m = _lib.Vit3MergerW(postshuffle=int(post))
+            for f, name in (("norm_w", "norm.weight"), ("norm_b", "norm.bias"), ("fc1_w", "linear_fc1.weight"),
+                            ("fc1_b", "linear_fc1.bias"), ("fc2_w", "linear_fc2.weight"), ("fc2_b", "linear_fc2.bias")):
+                keep[f"{key}.{f}"] = v(prefix + name).contiguous()
+                setattr(m, f, keep[f"{key}.{f}"].data_ptr())
+            return m
+
+        deep_idx = [int(i) for i in vc.deepstack_visual_indexes]
+        if len(deep_idx) > _lib.MAX_DEEPSTACK or sorted(set(deep_idx)) != deep_idx or any(i >= vc.depth for i in deep_idx):
+            raise _lib.O3VError(f"deepstack_visual_indexes {deep_idx}: need <= {_lib.MAX_DEEPSTACK} ascending block indexes")
+        self.vit3 = _lib.Vit3Desc(depth=vc.depth, hidden=hid, heads=heads, head_dim=hd, head_dim_pad=Dp, inter_pad=ip,
+                                  out_hidden=vc.out_hidden_size, patch_k_pad=vc.patch_k_pad, merge_unit=vc.merge_unit,
+                                  n_deep=len(deep_idx), patch_w=keep["v.patch_w"].data_ptr(), patch_b=keep["v.patch_b"].data_ptr(),
+                                  blocks=self.vit3_blocks, merger=merger("merger.", "v.m", False))
+        for k, idx in enumerate(deep_idx):
+            self.vit3.deep_index[k] = idx
+            self.vit3.deep[k] = merger(f"deepstack_merger_list.{k}.", f"v.ds{k}", True)
+
     def _check_shapes(self):
         vc, tc = self.cfg.vision, self.cfg.text
-        if vc.hidden_size % 64 or tc.hidden_size % 64 or (tc.num_attention_heads * tc.head_dim) % 64:
+        q3 = self.cfg.arch == "qwen3_vl"
+        if (vc.hidden_size % 64 and not q3) or tc.hidden_size % 64 or (tc.num_attention_heads * tc.head_dim) % 64:
             raise _lib.O3VError("hidden sizes must be multiples of 64 for the MFMA GEMM K loop")
-        if vc.head_dim not in (32, 64, 80, 128) or tc.head_dim not in (32, 64, 128):
+        if q3 and ((vc.num_heads * vc.head_dim_pad) % 64 or (vc.hidden_size * vc.merge_unit) % 64 or vc.hidden_size % 8 or vc.head_dim % 4):
+            raise _lib.O3VError("qwen3_vl vision widths: heads*pad16(head_dim) and 4*hidden must be multiples of 64")
+        if vc.head_dim_pad not in (32, 64, 80, 128) or tc.head_dim not in (32, 64, 128):
             raise _lib.O3VError(f"unsupported head_dim (vision {vc.head_dim}, text {tc.head_dim})")
         if tc.num_attention_heads // tc.num_key_value_heads > 8:
             raise _lib.O3VError("GQA group size > 8 not supported by the decode attention kernel")
@@ -254,16 +337,32 @@ def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02, head_std=N
     shapes = {}
     vh, vi = vc.hidden_size, vc.intermediate_size
     shapes["model.visual.patch_embed.proj.weight"] = (vh, vc.patch_k)
-    for i in range(vc.depth):
+    q3 = cfg.arch == "qwen3_vl"
+    mh = vh * vc.merge_unit
+    if q3:
+        shapes["model.visual.patch_embed.proj.bias"] = (vh,)
+        shapes["model.visual.pos_embed.weight"] = (vc.num_position_embeddings, vh)
+        for i in range(vc.depth):
+            b = f"model.visual.blocks.{i}."
+            shapes.update({b + "norm1.weight": (vh,), b + "norm1.bias": (vh,), b + "norm2.weight": (vh,), b + "norm2.bias": (vh,),
+                           b + "attn.qkv.weight": (3 * vh, vh), b + "attn.qkv.bias": (3 * vh,), b + "attn.proj.weight": (vh, vh),
+                           b + "attn.proj.bias": (vh,), b + "mlp.linear_fc1.weight": (vi, vh), b + "mlp.linear_fc1.bias": (vi,),
+                           b + "mlp.linear_fc2.weight": (vh, vi), b + "mlp.linear_fc2.bias": (vh,)})
+        for m, post in [("model.visual.merger.", False)] + [(f"model.visual.deepstack_merger_list.{k}.", True)
+                                                            for k in range(len(vc.deepstack_visual_indexes))]:
+            shapes.update({m + "norm.weight": (mh if post else vh,), m + "norm.bias": (mh if post else vh,),
+                           m + "linear_fc1.weight": (mh, mh), m + "linear_fc1.bias": (mh,),
+                           m + "linear_fc2.weight": (vc.out_hidden_size, mh), m + "linear_fc2.bias": (vc.out_hidden_size,)})
+    for i in range(0 if q3 else vc.depth):
         b = f"model.visual.blocks.{i}."
         shapes.update({b + "norm1.weight": (vh,), b + "norm2.weight": (vh,), b + "attn.qkv.weight": (3 * vh, vh),
                        b + "attn.qkv.bias": (3 * vh,), b + "attn.proj.weight": (vh, vh), b + "attn.proj.bias": (vh,),
                        b + "mlp.gate_proj.weight": (vi, vh), b + "mlp.gate_proj.bias": (vi,), b + "mlp.up_proj.weight": (vi, vh),
                        b + "mlp.up_proj.bias": (vi,), b + "mlp.down_proj.weight": (vh, vi), b + "mlp.down_proj.bias": (vh,)})
     m = "model.visual.merger."
-    mh = vh * vc.merge_unit
-    shapes.update({m + "ln_q.weight": (vh,), m + "mlp.0.weight": (mh, mh), m + "mlp.0.bias": (mh,),
-                   m + "mlp.2.weight": (vc.out_hidden_size, mh), m + "mlp.2.bias": (vc.out_hidden_size,)})
+    if not q3:
+        shapes.update({m + "ln_q.weight": (vh,), m + "mlp.0.weight": (mh, mh), m + "mlp.0.bias": (mh,),
+                       m + "mlp.2.weight": (vc.out_hidden_size, mh), m + "mlp.2.bias": (vc.out_hidden_size,)})
     H, nh, nkv, D, I, V = (tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim,
                            tc.intermediate_size, tc.vocab_size)
     shapes["model.language_model.embed_tokens.weight"] = (V, H)
@@ -275,6 +374,8 @@ def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02, head_std=N
                        b + "self_attn.v_proj.weight": (nkv * D, H), b + "self_attn.v_proj.bias": (nkv * D,),
                        b + "self_attn.o_proj.weight": (H, nh * D), b + "mlp.gate_proj.weight": (I, H),
                        b + "mlp.up_proj.weight": (I, H), b + "mlp.down_proj.weight": (H, I)})
+        if tc.qk_norm:
+            shapes.update({b + "self_attn.q_norm.weight": (D,), b + "self_attn.k_norm.weight": (D,)})
     shapes["model.language_model.norm.weight"] = (H,)
     shapes["lm_head.weight"] = (V, H)
 
@@ -283,6 +384,8 @@ def random_getter(cfg: O3VConfig, seed=1234, device="cuda", std=0.02, head_std=N
         if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layernorm.weight") \
                 or name.endswith("norm.weight") or name.endswith("ln_q.weight"):
             return torch.ones(shape, device=device, dtype=torch.bfloat16)
+        if name.endswith("norm1.bias") or name.endswith("norm2.bias") or name.endswith("norm.bias"):
+            return torch.zeros(shape, device=device, dtype=torch.bfloat16)
         t = torch.empty(shape, device=device, dtype=torch.bfloat16)
         t.normal_(0.0, head_std if (head_std is not None and name == "lm_head.weight") else std, generator=gen)
         return t

@@ -1,0 +1,156 @@
+"""GPU parity of the Qwen3-VL path (BASELINE config #5's family) against goldens G12 / G13, which the in-container
+transformers Qwen3VLForConditionalGeneration produced (tools/make_golden.py g12_g13_qwen3vl) in fp32 and bf16: merged visual
+tokens, every DeepStack feature, step logits along HF's greedy path, greedy ids.  G13 carries the 8B model's head geometry
+(ViT heads of 72 stored 80 wide, LLM heads of 128 at GQA 4:1, interleaved M-RoPE [24,20,20], three DeepStack taps).
+Bars as in test_gpu_model.py: no further from HF-fp32 than 2x what HF-bf16 itself is, ids bit-identical where HF's two
+precisions agree."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_models as fm
+import fixture_models_q3 as fq
+from test_gpu_model import LOGIT_ATOL, build_engine, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("g12_q3_tiny.npz", "tiny_q3_config", 0), ("g13_q3_medium.npz", "medium_q3_config", 2)]
+
+
+@pytest.fixture(scope="module")
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _load(golden_dir, fname, cfgname, wseed, **kw):
+    g = np.load(os.path.join(golden_dir, fname))
+    cfg = getattr(fq, cfgname)()
+    from open_o3_video_amd.config import O3VConfig
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, getter_from_dict
+    c = O3VConfig.from_dict(cfg)
+    assert c.arch == "qwen3_vl"
+    eng = O3VEngine(c, DeviceWeights(c, getter_from_dict(fq.make_weights(cfg, wseed)), "cuda", **kw))
+    return g, cfg, eng
+
+
+@pytest.mark.parametrize("fname,cfgname,wseed", CASES)
+def test_q3_vit_merged_and_deepstack(need_gpu, golden_dir, fname, cfgname, wseed):
+    g, cfg, eng = _load(golden_dir, fname, cfgname, wseed)
+    vis = eng.vit_forward(eng.pixels_from_processor(torch.from_numpy(g["pixel_values"])), g["grid"])
+    nd = len(cfg["vision_config"]["deepstack_visual_indexes"])
+    assert vis.shape == (1 + nd,) + g["f32_vit_merged"].shape
+    names = ["vit_merged"] + [f"deepstack_{k}" for k in range(nd)]
+    for k, name in enumerate(names):
+        f32 = torch.from_numpy(g["f32_" + name])
+        e_gpu, e_hf = rel_l2(vis[k], f32), rel_l2(torch.from_numpy(g["bf16_" + name]), f32)
+        print(f"{fname} {name}: rel-L2 vs HF-fp32 ours {e_gpu:.5f}, HF-bf16 {e_hf:.5f}")
+        assert e_gpu < 2.0 * e_hf + 1e-3, name
+
+
+@pytest.mark.parametrize("fname,cfgname,wseed", CASES)
+def test_q3_frames_path_equals_processor_rows(need_gpu, golden_dir, fname, cfgname, wseed):
+    """uint8 frames through o3v_patchify_ps (patch 16, mean = std = 0.5) == the HF processor's pixel_values rows cast to bf16."""
+    g, cfg, eng = _load(golden_dir, fname, cfgname, wseed)
+    px, grid = eng.pixels_from_frames(torch.from_numpy(g["frames"]))
+    assert np.array_equal(grid, g["grid"])
+    want = eng.pixels_from_processor(torch.from_numpy(g["pixel_values"]))
+    assert torch.equal(px, want)
+
+
+@pytest.mark.parametrize("fname,cfgname,wseed", CASES)
+def test_q3_greedy_ids_and_step_logits(need_gpu, golden_dir, fname, cfgname, wseed):
+    g, cfg, eng = _load(golden_dir, fname, cfgname, wseed)
+    n_new = g["f32_step_logits"].shape[1]
+    S = g["input_ids"].shape[1]
+    pv = torch.from_numpy(g["pixel_values"])
+    out = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=n_new,
+                       pad_token_id=cfg["pad_token_id"])
+    got = out.sequences.cpu().numpy()
+    # teacher-forced logits along HF-fp32's path
+    seq = g["f32_ids"]
+    lg = eng.forward_logits(seq[:, :-1], None, pixel_values=pv, image_grid_thw=g["grid"])[:, S - 1:S - 1 + n_new].float().cpu()
+    ref = torch.from_numpy(g["f32_step_logits"])
+    d_ours = (lg - ref).abs().max().item()
+    d_hf = (torch.from_numpy(g["bf16_step_logits"]) - ref).abs().max().item()
+    print(f"{fname}: step logits max|err| vs HF-fp32: ours {d_ours:.4f}, HF-bf16 {d_hf:.4f}; ids ours {got[0, S:].tolist()} "
+          f"HF-bf16 {g['bf16_ids'][0, S:].tolist()} HF-fp32 {g['f32_ids'][0, S:].tolist()}")
+    assert d_ours < LOGIT_ATOL and d_ours < 2.0 * d_hf + 0.02
+    # ids: equal to HF wherever the fp32 margin is safe against the measured logit error
+    want = g["f32_ids"][0, S:]
+    k = 0
+    while k < n_new and got[0, S + k] == want[k]:
+        k += 1
+    assert k == n_new or g["f32_margins"][0][k] <= 4 * max(d_ours, d_hf), f"ids diverge at step {k} at a safe margin"
+    if np.array_equal(g["bf16_ids"], g["f32_ids"]):
+        assert np.array_equal(got, g["f32_ids"])
+
+
+def test_q3_group_rollout_and_logps(need_gpu, golden_dir):
+    """The rollout entry points on a Qwen3-VL model: G sampled completions sharing one ViT pass + prefill, batch decode without
+    the fused attention block (qk-norm), and completion_logps == log-softmax of forward_logits at the completion tokens."""
+    g, cfg, eng = _load(golden_dir, *CASES[1])
+    pv = torch.from_numpy(g["pixel_values"])
+    S = g["input_ids"].shape[1]
+    out = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=10, do_sample=True,
+                       temperature=1.0, top_p=0.9, num_return_sequences=4, seed=5, pad_token_id=cfg["pad_token_id"])
+    seqs = out.sequences
+    assert seqs.shape == (4, S + 10) and len({tuple(r.tolist()) for r in seqs[:, S:]}) > 1
+    comp = seqs[:, S:]
+    lp = eng.completion_logps(g["input_ids"], comp, pixel_values=pv, image_grid_thw=g["grid"])
+    for r in range(4):
+        lg = eng.forward_logits(seqs[r:r + 1].cpu().numpy(), None, pixel_values=pv, image_grid_thw=g["grid"])
+        ref = torch.log_softmax(lg[0, S - 1:-1].float(), dim=-1).gather(1, comp[r].to(lg.device)[:, None])[:, 0]
+        assert (lp[r] - ref).abs().max().item() < 0.08, r
+    # greedy G=1 and G=2 agree on row 0 (fan-out of the prompt K/V incl. the DeepStack-modified hidden states)
+    a = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=8, pad_token_id=cfg["pad_token_id"])
+    b = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=8, num_return_sequences=2,
+                     pad_token_id=cfg["pad_token_id"])
+    assert torch.equal(a.sequences[0], b.sequences[0]) and torch.equal(b.sequences[0], b.sequences[1])
+
+
+def test_q3_prefix_reuse_with_deepstack(need_gpu, golden_dir):
+    """prefix_key reuse on Qwen3-VL: the second question prefills only its own tokens; DeepStack rows before the reused prefix
+    are already folded into the cached K/V, rows after it are added again -- ids equal the one-shot run."""
+    g, cfg, eng = _load(golden_dir, *CASES[1])
+    pv = torch.from_numpy(g["pixel_values"])
+    ids = g["input_ids"]
+    ids2 = ids.copy()
+    ids2[0, -3] = (ids2[0, -3] + 7) % 3000 + 10
+    kw = dict(pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=8, pad_token_id=cfg["pad_token_id"])
+    eng.generate(ids, None, prefix_key="v", **kw)
+    b = eng.generate(ids2, None, prefix_key="v", **kw)
+    assert b.timings["prefix_tokens_reused"] == ids.shape[1] - 3
+    eng.drop_prefix_cache()
+    c = eng.generate(ids2, None, **kw)
+    assert torch.equal(b.sequences, c.sequences)
+
+
+def test_q3_fp8_decode_rows(need_gpu, golden_dir):
+    """fp8 decode weights on the Qwen3-VL path (q/k/v as a plain fp8 linear + the qk-norm/rotation kernel): runs, and agrees with
+    the bf16-row engine on the first tokens when the weights are fp8-representable."""
+    from open_o3_video_amd.config import O3VConfig
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, dequantize_rows_fp8, getter_from_dict, quantize_rows_fp8
+    g = np.load(os.path.join(golden_dir, CASES[1][0]))
+    cfg = fq.medium_q3_config()
+    W = fq.make_weights(cfg, 2)
+    for k in list(W):
+        if k.startswith("model.language_model.layers.") and k.endswith("_proj.weight") or k == "lm_head.weight":
+            q8, sc = quantize_rows_fp8(W[k].to(torch.bfloat16))
+            W[k] = dequantize_rows_fp8(q8, sc)
+    c = O3VConfig.from_dict(cfg)
+    e1 = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda"))
+    e2 = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda", fp8_decode=True))
+    kw = dict(pixel_values=torch.from_numpy(g["pixel_values"]), image_grid_thw=g["grid"], max_new_tokens=10, pad_token_id=cfg["pad_token_id"])
+    a, b = e1.generate(g["input_ids"], None, **kw), e2.generate(g["input_ids"], None, **kw)
+    ga, gb = a.sequences[0, -10:].tolist(), b.sequences[0, -10:].tolist()
+    m = a.margins[0].tolist()
+    k = 0
+    while k < 10 and ga[k] == gb[k]:
+        k += 1
+    print(f"q3 fp8 rows: bf16 {ga} fp8 {gb} margins {np.round(m, 3).tolist()}")
+    assert k == 10 or m[k] < 2 * LOGIT_ATOL

@@ -118,7 +118,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/o3v.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.load().o3v_abi_version() == 4
+    assert _lib.load().o3v_abi_version() == 5
 
 
 def test_c_abi_argument_errors_without_gpu():
