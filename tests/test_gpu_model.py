@@ -359,6 +359,19 @@ def test_full_depth_true_width_vs_hf(need_gpu, golden_dir):
     print(f"G10 step logits (28 layers) vs HF-fp32: ours max {d_ours.max():.4f} mean {d_ours.mean():.4f}; "
           f"HF-bf16 max {d_hf.max():.4f} mean {d_hf.mean():.4f} (|logit| max {ref.abs().max():.2f}, HF paths agree for {same} steps)")
     assert d_ours.max().item() < 2.0 * d_hf.max().item() + 0.05 and d_ours.mean().item() < 2.0 * d_hf.mean().item() + 0.01
+    # The same rows left-padded by 37: the causal tiles start at other rows, so the online-softmax chunks and the split-K
+    # choice differ.  Both tilings are measured against HF-fp32 here (which of the two is closer was an open question of the
+    # full-size test P2, where no fp32 reference exists): neither is systematically closer -- both sit inside HF-bf16's own error.
+    pad = 37
+    seq = g["f32_ids"][:, :-1]
+    S = g["input_ids"].shape[1]
+    rows = np.concatenate([np.full((1, pad), cfg["pad_token_id"], dtype=np.int64), seq], axis=1)
+    mask = np.concatenate([np.zeros((1, pad), dtype=np.int64), np.ones_like(seq)], axis=1)
+    lgp = eng.forward_logits(rows, mask, pixel_values=pv, image_grid_thw=g["grid"])[:, pad + S - 1:pad + S - 1 + n_new].float().cpu()
+    d_pad = (lgp - ref).abs()
+    print(f"G10 left-padded by {pad}: vs HF-fp32 max {d_pad.max():.4f} mean {d_pad.mean():.4f}; padded vs unpadded max "
+          f"{(lgp - ours).abs().max():.4f} mean {(lgp - ours).abs().mean():.4f}")
+    assert d_pad.max().item() < 2.0 * d_hf.max().item() + 0.05 and d_pad.mean().item() < 2.0 * d_hf.mean().item() + 0.01
     out = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=n_new,
                        pad_token_id=cfg["pad_token_id"])
     got = out.sequences.cpu().numpy()[0, -n_new:]

@@ -171,3 +171,37 @@ if "3b" in which:
     cfg = O3VConfig.from_dict(qwen25vl_3b_dict())
     eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
     run("config#1 3B dims, 4x364x644 greedy", 4, 364, 644, 4 * (299 + 15) + 170, 256, repetition_penalty=1.05)
+
+if "q3" in which:
+    # BASELINE config #5's model family: Qwen3-VL-8B dims (random weights), 32 frames of 224x416 (7x13 = 91 tokens each),
+    # greedy B=1 with bf16 rows and with fp8 rows, then the N=16 self-consistency group (one ViT pass + one prefill).
+    from open_o3_video_amd.config import qwen3vl_8b_dict
+    del eng
+    torch.cuda.empty_cache()
+    cfg = O3VConfig.from_dict(qwen3vl_8b_dict())
+    H, W, NF, T = 224, 416, 32, 256
+    tpf = (H // 32) * (W // 32)
+    ids = build_prompt(cfg, NF, tpf, NF * (tpf + 15) + 170)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (NF, 3, H, W), generator=g, dtype=torch.uint8, device=dev)
+    for fp8 in (False, True):
+        eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, fp8_decode=fp8))
+        for tag, kw in (("greedy B=1", dict(repetition_penalty=1.05)),
+                        ("N=16 sampled group", dict(num_return_sequences=16, do_sample=True, top_p=0.95, temperature=1.0,
+                                                    repetition_penalty=1.05, seed=3))):
+            if fp8 and "N=16" in tag:
+                continue          # fp8 rows serve batch <= 3
+            eng.generate([ids], None, frames=frames, max_new_tokens=T, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = eng.generate([ids], None, frames=frames, max_new_tokens=T, return_margins=False, sync_timings=True, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rows = out.sequences.shape[0]
+            print(json.dumps({"config": f"Qwen3-VL-8B dims, {NF}x{H}x{W}, {tag}, {'fp8' if fp8 else 'bf16'} decode rows", "S": len(ids),
+                              "rows": rows, "new_tokens": T, "wall_s": round(dt, 3), "tokens_per_s": round(rows * T / dt, 1),
+                              "stage_ms": {k: round(v, 1) for k, v in out.timings.items()},
+                              "decode_ms_per_step": round(out.timings["decode_ms"] / T, 3),
+                              "weights_GB": round(eng.w.nbytes() / 1e9, 2)}), flush=True)
+        del eng
+        torch.cuda.empty_cache()
