@@ -265,3 +265,9 @@ class Qwen2_5_VLForConditionalGeneration:
 
 # the north-star text names the Qwen2-VL class; both resolve to the same engine
 Qwen2VLForConditionalGeneration = Qwen2_5_VLForConditionalGeneration
+
+
+class Qwen3VLForConditionalGeneration(Qwen2_5_VLForConditionalGeneration):
+    """The same surface over a Qwen3-VL checkpoint (BASELINE config #5's scorer, R:README.md:29,37): `config.json` with
+    model_type qwen3_vl selects the Qwen3-VL tower, DeepStack and q/k norm inside the engine; either class name loads either
+    family."""

@@ -92,6 +92,7 @@ class LLM:
             ge = load_generation_config(model).get("eos_token_id")
             self.generation_eos_ids = [] if ge is None else ([int(e) for e in ge] if isinstance(ge, (list, tuple)) else [int(ge)])
         self.engine, self.tokenizer = engine, tokenizer
+        self.image_factor = engine.cfg.vision.patch_size * engine.cfg.vision.spatial_merge_size   # 28; Qwen3-VL: 32
         self.max_num_seqs = int(max_num_seqs)   # requests of one generate() call decoded together (<= O3VEngine.MAX_ROWS)
         self.cfg = engine.cfg
         self.max_model_len = max_model_len
@@ -142,9 +143,9 @@ class LLM:
         if data.shape[1] != 3 and data.shape[-1] == 3:
             data = data.permute(0, 3, 1, 2)
         T, _, H, W = data.shape
-        # the HF image processor resizes every image with smart_resize(factor 28, min/max pixels) -- a no-op for frames
+        # the HF image processor resizes every image with smart_resize(factor = patch x merge: 28, Qwen3-VL 32; min/max pixels) -- a no-op for frames
         # that process_vision_info already sized
-        rh, rw = vp.smart_resize(H, W, 28, self.min_pixels, self.max_pixels)
+        rh, rw = vp.smart_resize(H, W, self.image_factor, self.min_pixels, self.max_pixels)
         if (rh, rw) != (H, W):
             data = vp.resize_frames_device(data, (rh, rw))   # antialiased bicubic on the GPU; frames stay on the device
         return data
@@ -196,7 +197,7 @@ class LLM:
         for req in inputs:
             prompt = req["prompt"] if isinstance(req, dict) else str(req)
             frames = self._frames(req.get("multi_modal_data") if isinstance(req, dict) else None)
-            tpf = 0 if frames is None else (frames.shape[2] // 28) * (frames.shape[3] // 28)
+            tpf = 0 if frames is None else (frames.shape[2] // self.image_factor) * (frames.shape[3] // self.image_factor)
             ids = self._tokenize(prompt, 0 if frames is None else frames.shape[0], tpf)
             if len(ids) + sp.max_tokens > self.max_model_len:
                 raise ValueError(f"prompt ({len(ids)}) + max_tokens ({sp.max_tokens}) exceeds max_model_len {self.max_model_len}")
