@@ -454,7 +454,7 @@ def main():
                                    f"(EOS suppressed, repetition_penalty 1.05), batch 1 per GPU, random-init bf16 weights",
                        "parallelism": par},
             "videos_per_min": round(n_gpus * args.steps / dt * 60.0, 2),
-            "stage_ms": {k: round(v, 2) for k, v in stages.items()},
+            "stage_ms": {k: round(v, 2) for k, v in stages.items() if k.endswith("_ms") or k == "prefix_tokens_reused"},
             "decode_tokens_per_sec_per_gpu": round(1e3 / dec_ms, 1) if dec_ms else None,
             "decode_step_hbm": {"algorithmic_bytes": int(wbytes + kv_bytes), "ms": round(dec_ms, 4),
                                 "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,

@@ -150,6 +150,13 @@ int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, con
 int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles, int rows_per_tile,
                    int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs, long v_bs,
                    long o_ts, float scale, o3v_stream_t stream);
+/* The same with a shared prompt entry: keys 0..prefix_len-1 of a tile come from Kpre / Vpre ([batch / rows_per_prefix] at
+ * stride p_bs, kv head at stride p_hs, token strides k_ts / v_ts), later keys from K / V whose rows then start at logical key
+ * prefix_len -- the completions of one prompt run behind ONE copy of its K/V (R:grpo_trainer.py:601-632 log-prob pass). */
+int o3v_attn_tiles_prefix(const void* Q, const void* K, const void* V, const void* Kpre, const void* Vpre, long p_hs, long p_bs,
+                          int prefix_len, int rows_per_prefix, void* O, const int* tiles, int n_tiles, int rows_per_tile, int Hq,
+                          int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
+                          float scale, o3v_stream_t stream);
 /* q_len == 1 attention against the cache [B,Hkv,Tmax,D]; part_o: f32[B*Hq*nsplit*D], part_ml: f32[B*Hq*nsplit*2] */
 int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                     const int* k_lo, int B, int Hq, int Hkv, int D, int ctx, int Tmax, int nsplit, float scale,
@@ -162,6 +169,13 @@ int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, void* out, fl
 int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                           const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
                           int nsplit_prefix, float scale, o3v_stream_t stream);
+/* The same without per-row copies of the prompt: Kpre / Vpre [B / rows_per_prompt][Hkv][prefix_cap][D] hold each prompt's
+ * K/V once, Kc / Vc [B][Hkv][Tmax][D] only the rows' generated tokens (logical key prefix_len + j in slot j).  G must divide
+ * rows_per_prompt.  Kpre == NULL: exactly o3v_attn_decode_group. */
+int o3v_attn_decode_group_prefix(const void* Q, const void* Kc, const void* Vc, const void* Kpre, const void* Vpre, int prefix_cap,
+                                 int rows_per_prompt, void* out, float* part_o, float* part_ml, const int* k_lo, int B, int G,
+                                 int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax, int nsplit_prefix, float scale,
+                                 o3v_stream_t stream);
 
 /* One launch for the attention half of a batch-1 decode layer (TF:692-757 first half; replaces o3v_gemv_norm_qkv_rope +
  * o3v_attn_decode + o3v_linear_decode(o_proj, RESIDUAL), bit-identical to them): the three stages are roles of the
@@ -314,12 +328,25 @@ size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
                     int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax, void* workspace,
                     size_t ws_bytes, o3v_stream_t stream);
-/* The same with DeepStack (Qwen3-VL, TF3:839-862): after decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]]
- * for i < n_ds (the visual rows among this call's B*S rows); ds_feat: n_deep tables, ds_stride bf16 elements apart. */
-int o3v_llm_prefill_deepstack(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
-                              int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax, const int* ds_rows,
-                              const int* ds_src, int n_ds, const void* ds_feat, int n_deep, long ds_stride, void* workspace,
-                              size_t ws_bytes, o3v_stream_t stream);
+/* Options of o3v_llm_prefill_ex (all optional; a zeroed struct == o3v_llm_prefill):
+ *  * DeepStack (Qwen3-VL, TF3:839-862): after decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]] for i < n_ds
+ *    (the visual rows among this call's B*S rows); ds_feat: n_deep tables, ds_stride bf16 elements apart.
+ *  * shared prompt entry: the first prefix_len of the `past` tokens of every row live ONCE per prompt in kprefix / vprefix
+ *    ([layers][B / rows_per_prefix][Hkv][prefix_cap][D]); kcache / vcache [layers][B][Hkv][Tmax][D] then hold only the tokens
+ *    behind them (this call's S tokens land in slots past - prefix_len ..) -- the G completions of one prompt run behind one
+ *    copy of its K/V (R:grpo_trainer.py:601-632).  Tile descriptors keep logical key indexes (k_len = past + S). */
+typedef struct {
+    const int *ds_rows, *ds_src;
+    int n_ds;
+    const void* ds_feat;
+    int n_deep;
+    long ds_stride;
+    const void *kprefix, *vprefix;
+    int prefix_len, prefix_cap, rows_per_prefix;
+} o3v_prefill_opts;
+int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
+                       int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax,
+                       const o3v_prefill_opts* opts, void* workspace, size_t ws_bytes, o3v_stream_t stream);
 /* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
 int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                  o3v_stream_t stream);
@@ -351,6 +378,11 @@ typedef struct {
                                     first step of a generate call.  Non-NULL selects the one-launch attention block
                                     (o3v_decode_attn_block) where its shapes allow (B == 1) */
     int top_k;                   /* sampling only: TopKLogitsWarper's k, 0 = off */
+    /* optional shared prompt entries (needs group > 1): kprefix / vprefix [layers][B / rows_per_prompt][Hkv][prefix_cap][D] hold
+     * each prompt's S keys ONCE; kcache / vcache [layers][B][Hkv][Tmax][D] then hold only the generated tokens (token `step` in
+     * slot `step`, Tmax >= Tnew - 1) instead of a copy of the prompt per row. */
+    const void *kprefix, *vprefix;
+    int prefix_cap, rows_per_prompt;
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

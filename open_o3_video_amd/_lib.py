@@ -61,7 +61,13 @@ class DecodeState(C.Structure):
                 ("x", vp), ("kcache", vp), ("vcache", vp), ("cosT", vp), ("sinT", vp), ("logits", vp), ("seen", vp),
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
-                ("ws_bytes", sz), ("group", i32), ("sync", vp), ("top_k", i32)]
+                ("ws_bytes", sz), ("group", i32), ("sync", vp), ("top_k", i32), ("kprefix", vp), ("vprefix", vp),
+                ("prefix_cap", i32), ("rows_per_prompt", i32)]
+
+
+class PrefillOpts(C.Structure):
+    _fields_ = [("ds_rows", vp), ("ds_src", vp), ("n_ds", i32), ("ds_feat", vp), ("n_deep", i32), ("ds_stride", i64),
+                ("kprefix", vp), ("vprefix", vp), ("prefix_len", i32), ("prefix_cap", i32), ("rows_per_prefix", i32)]
 
 
 # name -> argtypes (return type int unless listed in _RET)
@@ -113,8 +119,10 @@ SIGNATURES = {
     "o3v_llm_prefill": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp],
     "o3v_vit3_workspace_bytes": [C.POINTER(Vit3Desc), i32],
     "o3v_vit3_forward": [C.POINTER(Vit3Desc), vp, i32, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp],
-    "o3v_llm_prefill_deepstack": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64,
-                                  vp, sz, vp],
+    "o3v_llm_prefill_ex": [C.POINTER(LlmDesc), vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, C.POINTER(PrefillOpts), vp, sz, vp],
+    "o3v_attn_tiles_prefix": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64,
+                              i64, f32, vp],
+    "o3v_attn_decode_group_prefix": [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }

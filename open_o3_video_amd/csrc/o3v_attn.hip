@@ -48,12 +48,12 @@ struct AttnCfg {
 // RQ = 16-row query blocks per wave (1: 64-row tiles for the ragged ViT windows; 2: 128-row tiles for the LLM prefill,
 // where every K fragment read and every transposed V read from LDS feeds two MFMAs instead of one -- the kernel is
 // LDS-bandwidth-bound at RQ = 1).
-template <int D, int RQ>
+template <int D, int RQ, bool PFX = false>
 __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                          const TileDesc* __restrict__ tiles, long q_ts, long k_ts,
                                                          long k_hs, long k_bs, long v_ts, long v_hs, long v_bs, long o_ts,
-                                                         int n_rep, float scale_log2e) {
+                                                         int n_rep, float scale_log2e, PrefixRef pf, int P) {
     using C = AttnCfg<D>;
     // head_dim 128: K/V tiles go global -> LDS by DMA (global_load_lds, no registers), double buffered, so the loads of
     // tile kt+1 run under the MFMAs of tile kt and a tile costs one barrier instead of two.  Rows are 256 B = 16 chunks
@@ -99,6 +99,19 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
 
     const bf16_t* Kb = K + (size_t)td.batch * k_bs + (size_t)hk * k_hs + (size_t)td.k_row0 * k_ts;
     const bf16_t* Vb = V + (size_t)td.batch * v_bs + (size_t)hk * v_hs + (size_t)td.k_row0 * v_ts;
+    // PFX: keys below P come from the prompt entry shared by pf.rows batch rows; K / V then hold only the tokens behind it
+    // (logical key kr >= P in row kr - P).  Same token strides in both.
+    const bf16_t *Kp = nullptr, *Vp = nullptr;
+    if (PFX) {
+        const size_t po = (size_t)(td.batch / pf.rows) * pf.bs + (size_t)hk * pf.hs;
+        Kp = pf.K + po;
+        Vp = pf.V + po;
+        Kb -= (size_t)P * k_ts;
+        Vb -= (size_t)P * v_ts;
+    }
+    // (macros, not lambdas: a lambda called from the staging lambdas below keeps clang from emitting this kernel's host stub)
+#define krow(kr) (((PFX && (kr) < P) ? Kp : Kb) + (size_t)(kr) * k_ts)
+#define vrow(kr) (((PFX && (kr) < P) ? Vp : Vb) + (size_t)(kr) * v_ts)
 
     int k_end = td.k_len;
     if (td.causal_off >= 0) {
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
             int kr = kt * 64 + row;
             kr = kr < td.k_len ? kr : td.k_len - 1;
             kreg[SPLIT ? i : 0] = make_uint4(0, 0, 0, 0);
-            if (c < 64 * CPR && ch * 8 < D) kreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(Kb + (size_t)kr * k_ts + ch * 8);
+            if (c < 64 * CPR && ch * 8 < D) kreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(krow(kr) + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < NVC; ++i) {
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
             const int row = c / VPR, ch = c % VPR;
             int kr = kt * 64 + row;
             kr = kr < td.k_len ? kr : td.k_len - 1;
-            if (c < 64 * VPR) vreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(Vb + (size_t)kr * v_ts + ch * 8);
+            if (c < 64 * VPR) vreg[SPLIT ? i : 0] = *reinterpret_cast<const uint4*>(vrow(kr) + ch * 8);
         }
     };
     auto store_tile = [&]() {
@@ -155,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
             const int c = (lane & 15) ^ (row & 15);      // logical 16-byte chunk stored at slot (lane & 15) of the row
             int kr = kt * 64 + row;
             kr = kr < td.k_len ? kr : td.k_len - 1;
-            __builtin_amdgcn_global_load_lds(Kb + (size_t)kr * k_ts + c * 8, (lds_void_t*)(stage + instr * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(Vb + (size_t)kr * v_ts + c * 8, (lds_void_t*)(stage + 64 * 256 + instr * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(krow(kr) + c * 8, (lds_void_t*)(stage + instr * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(vrow(kr) + c * 8, (lds_void_t*)(stage + 64 * 256 + instr * 1024), 16, 0, 0);
         }
     };
     if (DMA && kt_lo < kt_hi) dma_tile(kt_lo, smem);
@@ -177,14 +190,14 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
                 int kr = kt * 64 + row;
                 kr = kr < td.k_len ? kr : td.k_len - 1;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (ch * 8 < D) v = *reinterpret_cast<const uint4*>(Kb + (size_t)kr * k_ts + ch * 8);
+                if (ch * 8 < D) v = *reinterpret_cast<const uint4*>(krow(kr) + ch * 8);
                 *reinterpret_cast<uint4*>(Kl + row * C::KSTRIDE + ch * 16) = v;
             }
             for (int c = threadIdx.x; c < 64 * VPR; c += 256) {
                 const int row = c / VPR, ch = c % VPR;
                 int kr = kt * 64 + row;
                 kr = kr < td.k_len ? kr : td.k_len - 1;
-                const uint4 v = *reinterpret_cast<const uint4*>(Vb + (size_t)kr * v_ts + ch * 8);
+                const uint4 v = *reinterpret_cast<const uint4*>(vrow(kr) + ch * 8);
                 *reinterpret_cast<uint4*>(Vl + row * C::VSTRIDE + ch * 16) = v;
             }
         }
@@ -296,6 +309,8 @@ __global__ __launch_bounds__(256, 2) void attn_tiles_kernel(const bf16_t* __rest
         }
     }
 }
+#undef krow
+#undef vrow
 
 // ------------------------------------------------------------------------------------------------
 // Decode attention.  grid (splits, Hkv, B), 4 waves.  A wave-iteration covers KPW = 64/(D/8) keys:
@@ -452,10 +467,10 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const bf16_t* __r
                                                                float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
                                                                int ctx, int Hq, int Hkv, int n_rep, long k_hs, long k_bs,
                                                                float scale_log2e, int kbeg, int nsplit_tot, int split_off,
-                                                               int G, int P) {
+                                                               int G, int P, PrefixRef pf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 x V slice, reused for the merge
     attn_decode_mfma_body<false>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, kbeg,
-                                 nsplit_tot, split_off, G, P, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, smem, AttnHandoff{});
+                                 nsplit_tot, split_off, G, P, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, smem, AttnHandoff{}, pf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,7 +487,7 @@ __device__ __forceinline__ void attn_decode_group_body(const bf16_t* __restrict_
                                                        float* __restrict__ part_ml, const int* __restrict__ k_lo_arr, int P, int G,
                                                        int Hq, int Hkv, int n_rep, long k_hs, long k_bs, float scale_log2e,
                                                        int nsplit_tot, const int split, const int nsplit, const int hk,
-                                                       const int grp) {
+                                                       const int grp, const PrefixRef pf) {
     constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE, QSTRIDE = 272, NQ = NQB * 16;
     constexpr int Q_BYTES = NQ * QSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // Q rows | 4 x V slice ; reused: so[NQ][128] | sm | sl
@@ -502,8 +517,9 @@ __device__ __forceinline__ void attn_decode_group_body(const bf16_t* __restrict_
     const int kw0 = split * chunk + wave * per_wave;
     int kw1 = kw0 + per_wave;
     kw1 = kw1 < P ? kw1 : P;
-    const bf16_t* Kb = Kc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
-    const bf16_t* Vb = Vc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
+    // the prefix: from the prompt's shared entry, or (legacy layout) from the cache row of the group's first sequence
+    const bf16_t* Kb = pf.K ? pf.K + (size_t)(b0 / pf.rows) * pf.bs + (size_t)hk * pf.hs : Kc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
+    const bf16_t* Vb = pf.K ? pf.V + (size_t)(b0 / pf.rows) * pf.bs + (size_t)hk * pf.hs : Vc + (size_t)b0 * k_bs + (size_t)hk * k_hs;
 
     float m_run[NQB], l_run[NQB];
     f32x4 o[NQB][8];
@@ -651,18 +667,19 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16_t* __
                                                                 float* __restrict__ part_ml, const int* __restrict__ k_lo_arr,
                                                                 int P, int G, int ctx, int Hq, int Hkv, int n_rep, long k_hs,
                                                                 long k_bs, float scale_log2e, int nsplit_prefix, int nsplit_own,
-                                                                int n_prefix) {
+                                                                int n_prefix, PrefixRef pf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nsplit_tot = nsplit_prefix + nsplit_own;
     int L = blockIdx.x;
     if (L < n_prefix) {
         attn_decode_group_body<NQB>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, P, G, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, nsplit_tot,
-                                    L % nsplit_prefix, nsplit_prefix, (L / nsplit_prefix) % Hkv, L / (nsplit_prefix * Hkv));
+                                    L % nsplit_prefix, nsplit_prefix, (L / nsplit_prefix) % Hkv, L / (nsplit_prefix * Hkv), pf);
     } else {
         L -= n_prefix;
+        // own keys P..ctx-1 (with a shared prompt entry the row's cache starts at logical key P: the body offsets it by its P)
         attn_decode_mfma_body<false>(Q, Kc, Vc, part_o, part_ml, k_lo_arr, ctx, Hq, Hkv, n_rep, k_hs, k_bs, scale_log2e, P,
-                                     nsplit_tot, nsplit_prefix, 1, 0, L % nsplit_own, nsplit_own, (L / nsplit_own) % Hkv,
-                                     L / (nsplit_own * Hkv), smem, AttnHandoff{});
+                                     nsplit_tot, nsplit_prefix, 1, pf.K ? P : 0, L % nsplit_own, nsplit_own, (L / nsplit_own) % Hkv,
+                                     L / (nsplit_own * Hkv), smem, AttnHandoff{}, pf);
     }
 }
 
@@ -685,19 +702,49 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 
 }  // namespace
 
+extern "C" int o3v_attn_tiles_prefix(const void* Q, const void* K, const void* V, const void* Kpre, const void* Vpre, long p_hs,
+                                     long p_bs, int prefix_len, int rows_per_prefix, void* O, const int* tiles, int n_tiles,
+                                     int rows_per_tile, int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs,
+                                     long v_ts, long v_hs, long v_bs, long o_ts, float scale, hipStream_t stream);
+extern "C" int o3v_attn_decode_group_prefix(const void* Q, const void* Kc, const void* Vc, const void* Kpre, const void* Vpre,
+                                            int prefix_cap, int rows_per_prompt, void* out, float* part_o, float* part_ml,
+                                            const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
+                                            int nsplit_prefix, float scale, hipStream_t stream);
+
 extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void* O, const int* tiles, int n_tiles,
                               int rows_per_tile, int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs,
                               long v_ts, long v_hs, long v_bs, long o_ts, float scale, hipStream_t stream) {
+    return o3v_attn_tiles_prefix(Q, K, V, nullptr, nullptr, 0, 0, 0, 1, O, tiles, n_tiles, rows_per_tile, Hq, n_rep, D, q_ts, k_ts, k_hs,
+                                 k_bs, v_ts, v_hs, v_bs, o_ts, scale, stream);
+}
+
+// Kpre/Vpre != NULL: keys 0..prefix_len-1 of a tile are read from the shared prompt entry of its batch row
+// ([batch / rows_per_prefix] at stride p_bs, kv head at stride p_hs, token stride k_ts / v_ts), keys from prefix_len on from
+// K / V, whose rows then start at logical key prefix_len (a completion's own tokens behind a prompt kept once).
+extern "C" int o3v_attn_tiles_prefix(const void* Q, const void* K, const void* V, const void* Kpre, const void* Vpre, long p_hs,
+                                     long p_bs, int prefix_len, int rows_per_prefix, void* O, const int* tiles, int n_tiles,
+                                     int rows_per_tile, int Hq, int n_rep, int D, long q_ts, long k_ts, long k_hs, long k_bs,
+                                     long v_ts, long v_hs, long v_bs, long o_ts, float scale, hipStream_t stream) {
     if (rows_per_tile != 64 && rows_per_tile != 128) return O3V_ERR_ARG;
     if (!Q || !K || !V || !O || !tiles || n_tiles < 0 || Hq <= 0 || n_rep <= 0 || (Hq % n_rep)) return O3V_ERR_ARG;
-    if ((q_ts & 7) || (k_ts & 7) || (v_ts & 7) || (k_hs & 7) || (v_hs & 7) || (o_ts & 3)) return O3V_ERR_SHAPE;
+    if ((Kpre == nullptr) != (Vpre == nullptr) || (Kpre && (prefix_len <= 0 || rows_per_prefix <= 0))) return O3V_ERR_ARG;
+    if ((q_ts & 7) || (k_ts & 7) || (v_ts & 7) || (k_hs & 7) || (v_hs & 7) || (o_ts & 3) || (p_hs & 7)) return O3V_ERR_SHAPE;
     if (n_tiles == 0) return O3V_OK;
     const float sl2 = scale * 1.4426950408889634f;
+    const PrefixRef pf{(const bf16_t*)Kpre, (const bf16_t*)Vpre, p_hs, p_bs, Kpre ? rows_per_prefix : 1};
+    const bool pfx = Kpre != nullptr;
     dim3 grid(n_tiles, Hq), block(256);
-#define O3V_AT1(DD, RQ)                                                                                               \
-    O3V_KLAUNCH((attn_tiles_kernel<DD, RQ>), grid, block, (DD == 128 ? 4 * 64 * 256 : AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES), stream, \
+#define O3V_AT2(DD, RQ, PF)                                                                                           \
+    O3V_KLAUNCH((attn_tiles_kernel<DD, RQ, PF>), grid, block, (DD == 128 ? 4 * 64 * 256 : AttnCfg<DD>::K_BYTES + AttnCfg<DD>::V_BYTES), stream, \
                        (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, (const TileDesc*)tiles, q_ts, \
-                       k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2)
+                       k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, n_rep, sl2, pf, prefix_len)
+#define O3V_AT1(DD, RQ)          \
+    do {                         \
+        if (pfx)                 \
+            O3V_AT2(DD, RQ, true);  \
+        else                     \
+            O3V_AT2(DD, RQ, false); \
+    } while (0)
 #define O3V_AT(DD)                       \
     do {                                 \
         if (rows_per_tile == 128)        \
@@ -714,6 +761,7 @@ extern "C" int o3v_attn_tiles(const void* Q, const void* K, const void* V, void*
     }
 #undef O3V_AT
 #undef O3V_AT1
+#undef O3V_AT2
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }
@@ -745,7 +793,8 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
                 O3V_AD(128);
             } else {
                 O3V_KLAUNCH(attn_decode_mfma_kernel, grid, block, 4 * 32 * 288, stream, (const bf16_t*)Q, (const bf16_t*)Kc,
-                            (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2, 0, nsplit, 0, 1, 0);
+                            (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, k_hs, k_bs, sl2, 0, nsplit, 0, 1, 0,
+                            PrefixRef{nullptr, nullptr, 0, 0, 1});
                 O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml,
                             (bf16_t*)out, nsplit);
             }
@@ -760,9 +809,25 @@ extern "C" int o3v_attn_decode(const void* Q, const void* Kc, const void* Vc, vo
 extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* Vc, void* out, float* part_o, float* part_ml,
                                      const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
                                      int nsplit_prefix, float scale, hipStream_t stream) {
+    return o3v_attn_decode_group_prefix(Q, Kc, Vc, nullptr, nullptr, 0, 1, out, part_o, part_ml, k_lo, B, G, Hq, Hkv, D, prefix_len, ctx,
+                                        Tmax, nsplit_prefix, scale, stream);
+}
+
+// Kpre/Vpre != NULL: the prompts' K/V are kept once, [B / rows_per_prompt][Hkv][prefix_cap][D]; Kc/Vc [B][Hkv][Tmax][D] then
+// hold only each row's generated tokens (logical key prefix_len + j in slot j).  G (the sub-group one workgroup serves) must
+// divide rows_per_prompt.
+extern "C" int o3v_attn_decode_group_prefix(const void* Q, const void* Kc, const void* Vc, const void* Kpre, const void* Vpre,
+                                            int prefix_cap, int rows_per_prompt, void* out, float* part_o, float* part_ml,
+                                            const int* k_lo, int B, int G, int Hq, int Hkv, int D, int prefix_len, int ctx, int Tmax,
+                                            int nsplit_prefix, float scale, hipStream_t stream) {
     if (!Q || !Kc || !Vc || !out || !part_o || !part_ml || B <= 0 || G <= 1 || (B % G) || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) ||
-        prefix_len <= 0 || ctx <= prefix_len || ctx > Tmax || nsplit_prefix == 0)
+        prefix_len <= 0 || ctx <= prefix_len || nsplit_prefix == 0 || (Kpre == nullptr) != (Vpre == nullptr))
         return O3V_ERR_ARG;
+    if (Kpre ? (ctx - prefix_len > Tmax || prefix_len > prefix_cap || rows_per_prompt <= 0 || (rows_per_prompt % G) || (B % rows_per_prompt))
+             : ctx > Tmax)
+        return O3V_ERR_ARG;
+    const PrefixRef pf{(const bf16_t*)Kpre, (const bf16_t*)Vpre, (long)prefix_cap * D, (long)Hkv * prefix_cap * D,
+                       Kpre ? rows_per_prompt : 1};
     const int n_rep = Hq / Hkv;
     if (D != 128) return O3V_ERR_SHAPE;
     if (nsplit_prefix > 0 && G * n_rep > 64) return O3V_ERR_SHAPE;  // the one-pass kernel holds the group in 64 MFMA columns
@@ -772,7 +837,7 @@ extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* 
         if (ns > 64) return O3V_ERR_ARG;
         O3V_KLAUNCH(attn_decode_mfma_kernel, dim3(ns, Hkv, B), dim3(256), 4 * 32 * 288, stream, (const bf16_t*)Q, (const bf16_t*)Kc,
                     (const bf16_t*)Vc, part_o, part_ml, k_lo, ctx, Hq, Hkv, n_rep, (long)Tmax * D, (long)Hkv * Tmax * D,
-                    scale * 1.4426950408889634f, 0, ns, 0, G, prefix_len);
+                    scale * 1.4426950408889634f, 0, ns, 0, G, prefix_len, pf);
         O3V_KLAUNCH((attn_decode_combine_kernel<128>), dim3(B * Hq), dim3(128), 0, stream, part_o, part_ml, (bf16_t*)out, ns);
         O3V_CHECK_LAUNCH();
         return O3V_OK;
@@ -791,7 +856,7 @@ extern "C" int o3v_attn_decode_group(const void* Q, const void* Kc, const void* 
                              ? (NQB * 16 * 272 + 4 * 32 * 288)                                                              \
                              : (NQB * 16 * 128 * 4 + 5 * NQB * 16 * 4)),                                                    \
                 stream, (const bf16_t*)Q, (const bf16_t*)Kc, (const bf16_t*)Vc, part_o, part_ml, k_lo, prefix_len, G, ctx, Hq, \
-                Hkv, n_rep, k_hs, k_bs, sl2, nsplit_prefix, nsplit_own, n_prefix)
+                Hkv, n_rep, k_hs, k_bs, sl2, nsplit_prefix, nsplit_own, n_prefix, pf)
     if (nqb == 1)
         O3V_AG(1);
     else if (nqb == 2)

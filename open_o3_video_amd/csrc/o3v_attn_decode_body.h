@@ -90,6 +90,15 @@ struct AttnHandoff {
     } while (0)
 #endif
 
+// A prompt's K/V kept ONCE for the rows that share it (the G completions of a prompt): [prompts][Hkv][cap][D].  K == nullptr:
+// every row's cache holds its own copy of the prompt (legacy layout).  With it, a row's own cache holds only the tokens
+// generated after the prompt: logical key kr >= P lives in row kr - P of the row's cache.
+struct PrefixRef {
+    const bf16_t *K, *V;
+    long hs, bs;  // head / prompt strides in elements
+    int rows;     // decode rows per prompt: row b reads prompt b / rows
+};
+
 template <bool FUSED>
 __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
                                                       const bf16_t* __restrict__ Vc, float* __restrict__ part_o,
@@ -97,7 +106,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__
                                                       int Hq, int Hkv, int n_rep, long k_hs, long k_bs, float scale_log2e,
                                                       int kbeg, int nsplit_tot, int split_off, int G, int P, const int split,
                                                       const int nsplit, const int hk, const int b, char* smem,
-                                                      const AttnHandoff& ho) {
+                                                      const AttnHandoff& ho, const PrefixRef pf = PrefixRef{nullptr, nullptr, 0, 0, 1}) {
     // keys kbeg..ctx-1 of every row; partials go to slots split_off.. of the row's nsplit_tot (the slots before
     // split_off belong to attn_decode_group_kernel when the rows of a group share their first kbeg keys)
     constexpr int D = 128, KT = 32, VSTRIDE = 288, V_BYTES = KT * VSTRIDE;  // 9216 B per wave; smem: 4 x V slice, reused for the merge
@@ -120,6 +129,13 @@ __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__
     const size_t lead = G > 1 ? (size_t)(b - (b / G) * G) * k_bs : 0;
     const bf16_t* Kl = Kb - lead;
     const bf16_t* Vl0 = Vb - lead;
+    if (pf.K) {  // shared prompt K/V: keys below P from the prompt's entry, the row's own cache starts at logical key P
+        const size_t po = (size_t)(b / pf.rows) * pf.bs + (size_t)hk * pf.hs;
+        Kl = pf.K + po;
+        Vl0 = pf.V + po;
+        Kb -= (size_t)P * D;
+        Vb -= (size_t)P * D;
+    }
 
     bf16x8 kf[2][4];
     u32x4 vreg[8];

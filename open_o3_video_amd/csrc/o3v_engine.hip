@@ -259,44 +259,58 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
 extern "C" int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
                                int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int past,
                                int Tmax, void* workspace, size_t ws_bytes, o3v_stream_t s) {
-    return o3v_llm_prefill_deepstack(d, x, cosT, sinT, tiles, n_tiles, rows_per_tile, kcache, vcache, B, S, past, Tmax, nullptr,
-                                     nullptr, 0, nullptr, 0, 0, workspace, ws_bytes, s);
+    return o3v_llm_prefill_ex(d, x, cosT, sinT, tiles, n_tiles, rows_per_tile, kcache, vcache, B, S, past, Tmax, nullptr, workspace,
+                              ws_bytes, s);
 }
 
-// ds_*: DeepStack (TF3:839-862).  After decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]] for the n_ds visual
-// rows of this call; ds_feat holds n_deep tables of ds_stride elements each.
-extern "C" int o3v_llm_prefill_deepstack(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles,
-                                         int n_tiles, int rows_per_tile, void* kcache, void* vcache, int B, int S, int past,
-                                         int Tmax, const int* ds_rows, const int* ds_src, int n_ds, const void* ds_feat,
-                                         int n_deep, long ds_stride, void* workspace, size_t ws_bytes, o3v_stream_t s) {
+// opts (may be NULL), see o3v_prefill_opts in include/o3v.h:
+//  * DeepStack (TF3:839-862): after decoder layer l < n_deep, x[ds_rows[i]] += ds_feat[l][ds_src[i]] for the n_ds visual rows.
+//  * shared prompt entry: the first prefix_len of the `past` tokens live ONCE per prompt in kprefix / vprefix; kcache / vcache
+//    then hold only the tokens behind them (the S new ones land in slots past - prefix_len ..).
+extern "C" int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
+                                  int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax,
+                                  const o3v_prefill_opts* opts, void* workspace, size_t ws_bytes, o3v_stream_t s) {
     if (!d || !x || !cosT || !sinT || !tiles || !kcache || !vcache || !workspace) return O3V_ERR_ARG;
-    if (n_ds < 0 || n_deep < 0 || (n_ds > 0 && n_deep > 0 && (!ds_rows || !ds_src || !ds_feat))) return O3V_ERR_ARG;
-    if (B <= 0 || S <= 0 || past < 0 || past + S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
+    const o3v_prefill_opts none = {};
+    const o3v_prefill_opts& o = opts ? *opts : none;
+    const int n_ds = o.n_ds, n_deep = o.n_deep;
+    if (n_ds < 0 || n_deep < 0 || (n_ds > 0 && n_deep > 0 && (!o.ds_rows || !o.ds_src || !o.ds_feat))) return O3V_ERR_ARG;
+    const bool pfx = o.kprefix != nullptr;
+    if (pfx && (!o.vprefix || o.prefix_len <= 0 || o.prefix_len > past || o.prefix_len > o.prefix_cap || o.rows_per_prefix <= 0 ||
+                (B % o.rows_per_prefix)))
+        return O3V_ERR_ARG;
+    const int own_past = pfx ? past - o.prefix_len : past;  // tokens already in this call's own caches
+    if (B <= 0 || S <= 0 || past < 0 || own_past + S > Tmax || d->kv_heads <= 0 || (d->heads % d->kv_heads)) return O3V_ERR_ARG;
     const int rows = B * S, H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter;
     const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
     LlmWs w;
     if (ws_bytes < o3v_llm_workspace_bytes(d, rows) || !carve_llm(d, rows, workspace, ws_bytes, w)) return O3V_ERR_WORKSPACE;
     const float scale = 1.0f / sqrtf((float)D);
     const size_t layer_stride = (size_t)B * Hkv * Tmax * D * 2;
+    const size_t pre_stride = pfx ? (size_t)(B / o.rows_per_prefix) * Hkv * o.prefix_cap * D * 2 : 0;
+    const long p_hs = (long)o.prefix_cap * D, p_bs = (long)Hkv * o.prefix_cap * D;
     for (int l = 0; l < d->layers; ++l) {
         const o3v_llm_layer_w& lw = d->layer[l];
         char* kc = (char*)kcache + l * layer_stride;
         char* vc = (char*)vcache + l * layer_stride;
+        const char* kp = pfx ? (const char*)o.kprefix + l * pre_stride : nullptr;
+        const char* vp = pfx ? (const char*)o.vprefix + l * pre_stride : nullptr;
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         if (lw.q_norm)
-            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax,
-                                        S, 0, s));
+            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, cosT, sinT, w.q, kc, vc, own_past, rows, S, Hq, Hkv, D,
+                                        Tmax, S, 0, s));
         else
-            TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
-        TRY(o3v_attn_tiles(w.q, kc, vc, w.att, tiles, n_tiles, rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D,
-                           (long)Tmax * D, (long)Hkv * Tmax * D, QD, scale, s));
+            TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, own_past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
+        TRY(o3v_attn_tiles_prefix(w.q, kc, vc, kp, vp, p_hs, p_bs, o.prefix_len, pfx ? o.rows_per_prefix : 1, w.att, tiles, n_tiles,
+                                  rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D, (long)Tmax * D,
+                                  (long)Hkv * Tmax * D, QD, scale, s));
         TRY(linear(w.att, lw.o_w, nullptr, x, x, rows, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         TRY(o3v_rmsnorm(x, lw.ln2, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.gu_w, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s, nullptr, 0, d->gemm_tile));
         TRY(linear(w.mlp, lw.down_w, nullptr, x, x, rows, H, I, I, H, H, O3V_EPI_RESIDUAL, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         if (l < n_deep && n_ds > 0)
-            TRY(o3v_add_rows(x, ds_rows, ds_src, (const char*)ds_feat + (size_t)l * ds_stride * 2, n_ds, H, s));
+            TRY(o3v_add_rows(x, o.ds_rows, o.ds_src, (const char*)o.ds_feat + (size_t)l * o.ds_stride * 2, n_ds, H, s));
     }
     return O3V_OK;
 }
@@ -333,8 +347,14 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         !st->cur_tok || !st->finished || !st->out_ids || !st->part_o || !st->part_ml || !st->workspace)
         return O3V_ERR_ARG;
     const int B = st->B;
-    if (B <= 0 || B > 16 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew || st->S + st->Tnew > st->Tmax + 1)
+    // shared prompt entries: the caches hold only the generated tokens (slot = step), the prompt K/V live once per prompt
+    const bool pfx = st->kprefix != nullptr;
+    if (B <= 0 || B > 16 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew ||
+        (pfx ? st->Tnew : st->S + st->Tnew) > st->Tmax + 1)
         return O3V_ERR_ARG;
+    if (pfx && (!st->vprefix || st->group <= 1 || st->rows_per_prompt <= 0 || (B % st->rows_per_prompt) || st->S > st->prefix_cap))
+        return O3V_ERR_ARG;
+    const int slot0 = pfx ? 0 : st->S;  // cache slot of generated token 0
     if (!st->sample_scratch) return O3V_ERR_ARG;
     const int H = d->hidden, Hq = d->heads, Hkv = d->kv_heads, D = d->head_dim, I = d->inter, V = d->vocab;
     const int QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
@@ -343,6 +363,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         return O3V_ERR_WORKSPACE;
     const float scale = 1.0f / sqrtf((float)D);
     const size_t layer_stride = (size_t)B * Hkv * st->Tmax * D * 2;
+    const size_t pre_stride = pfx ? (size_t)(B / st->rows_per_prompt) * Hkv * st->prefix_cap * D * 2 : 0;
     // B >= 4 rows run on the matrix-core linears, which stage the normalised x of a fused RMSNorm in LDS (57 KB at B=8, 115 KB
     // at B=16: two blocks, then one, per CU).  With a separate 3 us norm launch the linears are LDS-free: gate/up 54 -> 44 us
     // at B=8, 75 -> 50 us at B=16 (profiles/r01_m8_linear.txt).  Whole step, 7B: B=4 3.56 -> 3.61 ms (worse: two more
@@ -366,22 +387,24 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             else
                 TRY(o3v_linear_decode(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
                                       O3V_EPI_NONE, s));
-            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, st->cosT, st->sinT, w.q, kc, vc, st->S + step, B, 1, Hq,
+            TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, st->cosT, st->sinT, w.q, kc, vc, slot0 + step, B, 1, Hq,
                                         Hkv, D, st->Tmax, st->Tnew, step, s));
         } else if (fp8) {
             TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
-                                           kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+                                           kc, vc, slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         } else if (norm_apart) {
             TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
             TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
-                                       st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+                                       slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         } else {
             TRY(o3v_gemv_norm_qkv_rope(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
-                                       kc, vc, st->S + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
+                                       kc, vc, slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         }
         if (st->group > 1)  // the rows of a group share the prompt K/V: read it once per group
-            TRY(o3v_attn_decode_group(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D, st->S,
-                                      st->S + step + 1, st->Tmax, st->nsplit, scale, s));
+            TRY(o3v_attn_decode_group_prefix(w.q, kc, vc, pfx ? (const char*)st->kprefix + l * pre_stride : nullptr,
+                                             pfx ? (const char*)st->vprefix + l * pre_stride : nullptr, st->prefix_cap,
+                                             st->rows_per_prompt, w.att, st->part_o, st->part_ml, st->k_lo, B, st->group, Hq, Hkv, D,
+                                             st->S, st->S + step + 1, st->Tmax, st->nsplit, scale, s));
         else
             TRY(o3v_attn_decode(w.q, kc, vc, w.att, st->part_o, st->part_ml, st->k_lo, B, Hq, Hkv, D, st->S + step + 1, st->Tmax,
                                 st->nsplit, scale, s));
@@ -402,7 +425,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                         st->n_eos, st->pad_id, B, V, V, st->rep_penalty, step, st->Tnew, st->sample_scratch,
                                         d->embed, st->x, H, s));
         if (skip_last_forward && i == n_steps - 1) break;
-        if (st->S + step >= st->Tmax) return O3V_ERR_ARG;
+        if (slot0 + step >= st->Tmax) return O3V_ERR_ARG;
         // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
         if (st->do_sample) TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
         for (int l = 0; l < d->layers; ++l) {

@@ -213,31 +213,37 @@ class O3VEngine:
                 torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
 
     def prefill(self, x: torch.Tensor, pos3: np.ndarray, pad: Sequence[int], B: int, S: int, kc, vc, past: int = 0,
-                deepstack=None):
+                deepstack=None, prefix=None):
         """Runs the prompt through the LLM (TF:790-872); x [B*S,H] becomes the last layer's residual stream.
-        past > 0: slots 0..past-1 of the caches already hold a prompt prefix (HF `past_key_values` semantics);
-        x / pos3 are the S tokens after it.  deepstack = (input_ids, vis [1+n_deep, n, H]) of a Qwen3-VL prompt: the DeepStack
-        features are added after the first decoder layers at the visual rows (TF3:839-862)."""
+        past > 0: `past` tokens per row are already computed (HF `past_key_values` semantics); x / pos3 are the S tokens
+        after them.  By default they sit in slots 0..past-1 of kc / vc.  prefix = (kc0, vc0, rows_per_prefix): they sit ONCE
+        per prompt in kc0 / vc0 [layers, B/rows_per_prefix, Hkv, >=past, D] instead, and kc / vc hold only the new tokens (the
+        G completions of a prompt behind one copy of its K/V).  deepstack = (input_ids, vis [1+n_deep, n, H]) of a Qwen3-VL
+        prompt: the DeepStack features are added after the first decoder layers at the visual rows (TF3:839-862)."""
         Tmax = kc.shape[3]
-        if deepstack is not None and deepstack[1] is not None and deepstack[1].dim() == 3 and deepstack[1].shape[0] > 1:
-            ids_all, vis = deepstack
-            rows, src = indexing.deepstack_rows(ids_all, self.cfg.image_token_id, first=past)
-            cos, sin = self.mrope_table(pos3.reshape(3, B * S))
-            tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad, past=past)).to(self.dev)
-            nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            rows_d, src_d = torch.from_numpy(rows).to(self.dev), torch.from_numpy(src).to(self.dev)
-            feat = vis[1:]
-            _lib.call("o3v_llm_prefill_deepstack", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
-                      indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, int(past), Tmax, _ptr(rows_d), _ptr(src_d), int(rows.shape[0]),
-                      _ptr(feat), int(feat.shape[0]), int(feat.stride(0)), _ptr(ws), nbytes, _stream())
-            return x
         cos, sin = self.mrope_table(pos3.reshape(3, B * S))
         tiles = torch.from_numpy(indexing.prefill_tiles(B, S, pad, past=past)).to(self.dev)
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-        _lib.call("o3v_llm_prefill", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
-                  indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, int(past), Tmax, _ptr(ws), nbytes, _stream())
+        opts = _lib.PrefillOpts()
+        keep = []
+        if deepstack is not None and deepstack[1] is not None and deepstack[1].dim() == 3 and deepstack[1].shape[0] > 1:
+            ids_all, vis = deepstack
+            rows, src = indexing.deepstack_rows(ids_all, self.cfg.image_token_id, first=past)
+            rows_d, src_d = torch.from_numpy(rows).to(self.dev), torch.from_numpy(src).to(self.dev)
+            feat = vis[1:]
+            keep += [rows_d, src_d, feat]
+            opts.ds_rows, opts.ds_src, opts.n_ds = rows_d.data_ptr(), src_d.data_ptr(), int(rows.shape[0])
+            opts.ds_feat, opts.n_deep, opts.ds_stride = feat.data_ptr(), int(feat.shape[0]), int(feat.stride(0))
+        if prefix is not None:
+            kc0, vc0, rpp = prefix
+            if kc0.shape[3] < past or not kc0.is_contiguous() or not vc0.is_contiguous() or B % rpp or kc0.shape[1] != B // rpp:
+                raise ValueError("prefix caches do not match the rows they serve")
+            opts.kprefix, opts.vprefix = kc0.data_ptr(), vc0.data_ptr()
+            opts.prefix_len, opts.prefix_cap, opts.rows_per_prefix = int(past), int(kc0.shape[3]), int(rpp)
+        _lib.call("o3v_llm_prefill_ex", C.byref(self.w.llm), _ptr(x), _ptr(cos), _ptr(sin), _ptr(tiles), tiles.shape[0],
+                  indexing.PREFILL_TILE, _ptr(kc), _ptr(vc), B, S, int(past), Tmax, C.byref(opts), _ptr(ws), nbytes, _stream())
+        del keep
         return x
 
     def head(self, x_rows: torch.Tensor) -> torch.Tensor:
@@ -309,8 +315,13 @@ class O3VEngine:
         else:
             p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
             pos, deltas = np.broadcast_to(p1[None], (3, B0, S)).copy(), np.zeros(B0, dtype=np.int64)
-        Tmax = S + T
+        # G completions of a prompt share its K/V (head_dim 128, own keys in <= 32 splits): the prompt's K/V is kept ONCE
+        # (kc0 / vc0) and every row's cache holds only its generated tokens -- no G-fold copy of the prompt
+        own_splits = (T + 127) // 128
+        shared_prompt = G > 1 and tc.head_dim == 128 and own_splits <= 32 and self.group_attention
+        Tmax = T if shared_prompt else S + T
         kc, vc = self.alloc_cache(B, Tmax)
+        kc0 = vc0 = None
         past = 0
         use_prefix = prefix_key is not None and B0 == 1 and int(pad[0]) == 0
         if use_prefix:
@@ -326,14 +337,16 @@ class O3VEngine:
                 kc0[:, :, :, :past].copy_(ent["k"][:, :, :, :past])
                 vc0[:, :, :, :past].copy_(ent["v"][:, :, :, :past])
             self.prefill(x, pos[:, :, past:], pad, B0, S - past, kc0, vc0, past=past, deepstack=ds)
-            # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
-            # (a broadcast copy into the [layers, B0, G, ...] view of the caches: no G-times temporary)
-            shp = (kc.shape[0], B0, G) + tuple(kc.shape[2:])
-            kc.view(shp)[:, :, :, :, :S].copy_(kc0[:, :, None])
-            vc.view(shp)[:, :, :, :, :S].copy_(vc0[:, :, None])
+            if not shared_prompt:
+                # KV fan-out: completion g of prompt b is row b*G+g (repeat_interleave order, R:grpo_trainer.py:586)
+                # (a broadcast copy into the [layers, B0, G, ...] view of the caches: no G-times temporary)
+                shp = (kc.shape[0], B0, G) + tuple(kc.shape[2:])
+                kc.view(shp)[:, :, :, :, :S].copy_(kc0[:, :, None])
+                vc.view(shp)[:, :, :, :, :S].copy_(vc0[:, :, None])
             if use_prefix:
                 self._prefix_store(prefix_key, ids[0], kc0, vc0)
-            del kc0, vc0
+            if not shared_prompt:
+                kc0 = vc0 = None
         tm["prefix_tokens_reused"] = past
         last = x.view(B0, S - past, -1)[:, -1, :]               # left padding: every row ends at S-1
         logits0 = self.head(last)                               # [B0, V]
@@ -366,12 +379,10 @@ class O3VEngine:
         # G completions of a prompt share its K/V: the group kernel reads the prompt keys once per group (head_dim 128,
         # G * n_rep <= 64 query rows per kv head, prefix splits + own-key splits <= 64)
         n_rep = tc.num_attention_heads // tc.num_key_value_heads
-        own_splits = (T + 127) // 128
-        group = G if (G > 1 and tc.head_dim == 128 and own_splits <= 32 and self.group_attention) else 0
+        group = G if shared_prompt else 0
         mode = self.group_attention_mode
         if group:
             # the one-pass kernel holds a sub-group's query rows as MFMA columns (<= 64); sub-groups of 4 rows measured best
-            # (every row carries its own copy of the prompt K/V, so any row can lead a sub-group)
             sub = max(d for d in range(1, G + 1) if G % d == 0 and d <= 4 and d * n_rep <= 64)
             if mode == "auto":
                 # measured, 7B dims, ms per decode step (tools/measure_configs.py rollout / rollout_eval), per-row kernel reading
@@ -408,7 +419,10 @@ class O3VEngine:
                               part_o=part_o.data_ptr(), part_ml=part_ml.data_ptr(),
                               sample_scratch=scratch.data_ptr(), workspace=ws.data_ptr(),
                               ws_bytes=nbytes, group=group, sync=0 if sync is None else sync.data_ptr(),
-                              top_k=max(0, int(top_k or 0)))
+                              top_k=max(0, int(top_k or 0)), kprefix=kc0.data_ptr() if shared_prompt else 0,
+                              vprefix=vc0.data_ptr() if shared_prompt else 0, prefix_cap=S if shared_prompt else 0,
+                              rows_per_prompt=G if shared_prompt else 0)
+        tm["kv_cache_bytes"] = int((kc.numel() + vc.numel() + (kc0.numel() + vc0.numel() if shared_prompt else 0)) * 2)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
         use_eos = len(eos_token_ids) > 0
@@ -555,14 +569,13 @@ class O3VEngine:
         rows[:, 0] = x_last
         if T > 1:
             # the first T-1 completion tokens of every row behind the shared prompt K/V
-            kc, vc = self.alloc_cache(G, S + T - 1)
-            kc[:, :, :, :S].copy_(kc0.expand(-1, G, -1, -1, -1))
-            vc[:, :, :, :S].copy_(vc0.expand(-1, G, -1, -1, -1))
+            # (their caches hold only their own T-1 tokens; the prompt's K/V is read from kc0 / vc0, kept once)
+            kc, vc = self.alloc_cache(G, T - 1)
             ctok = comp[:, :T - 1].to(self.dev, torch.int32).contiguous().view(-1)
             xc = torch.empty((G * (T - 1), H), dtype=torch.bfloat16, device=self.dev)
             _lib.call("o3v_embed_tokens", _ptr(self.w.t["l.embed"]), _ptr(ctok), _ptr(xc), G * (T - 1), H, _stream())
             dpos = np.repeat(indexing.decode_positions(mask, deltas, T - 1), G, axis=1)      # [3, G, T-1]
-            self.prefill(xc, dpos, np.repeat(pad, G), G, T - 1, kc, vc, past=S)
+            self.prefill(xc, dpos, np.repeat(pad, G), G, T - 1, kc, vc, past=S, prefix=(kc0, vc0, G))
             rows[:, 1:] = xc.view(G, T - 1, H)
             del kc, vc, xc
         del kc0, vc0

@@ -84,6 +84,25 @@ def attn_decode_group(q, kc, vc, k_lo, G, prefix_len, ctx, nsplit_prefix, scale)
     return out
 
 
+def attn_decode_group_prefix(q, kc_own, vc_own, kpre, vpre, rows_per_prompt, k_lo, G, prefix_len, ctx, nsplit_prefix, scale):
+    """kc_own / vc_own [B, Hkv, Tmax_own, D]: generated tokens only; kpre / vpre [B / rows_per_prompt, Hkv, cap, D]."""
+    B, Hq, D = q.shape
+    _, Hkv, Tmax, _ = kc_own.shape
+    out = torch.empty_like(q)
+    po = torch.empty(B * Hq * 64 * D, dtype=torch.float32, device=q.device)
+    pm = torch.empty(B * Hq * 64 * 2, dtype=torch.float32, device=q.device)
+    _lib.call("o3v_attn_decode_group_prefix", _p(q), _p(kc_own), _p(vc_own), _p(kpre), _p(vpre), kpre.shape[2], rows_per_prompt, _p(out),
+              _p(po), _p(pm), _p(k_lo), B, G, Hq, Hkv, D, prefix_len, ctx, Tmax, nsplit_prefix, float(scale), _s())
+    return out
+
+
+def attn_tiles_prefix(q, k, v, kpre, vpre, p_hs, p_bs, prefix_len, rows_per_prefix, tiles, Hq, n_rep, D, q_ts, k_ts, k_hs, k_bs, v_ts,
+                      v_hs, v_bs, out, o_ts, scale, rows_per_tile=64):
+    _lib.call("o3v_attn_tiles_prefix", _p(q), _p(k), _p(v), _p(kpre), _p(vpre), p_hs, p_bs, prefix_len, rows_per_prefix, _p(out),
+              _p(tiles), tiles.shape[0], rows_per_tile, Hq, n_rep, D, q_ts, k_ts, k_hs, k_bs, v_ts, v_hs, v_bs, o_ts, float(scale), _s())
+    return out
+
+
 def gather_rows(src, idx):
     out = torch.empty((idx.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
     _lib.call("o3v_gather_rows", _p(src), _p(idx), _p(out), idx.shape[0], src.shape[1] * src.element_size(), _s())

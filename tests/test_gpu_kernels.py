@@ -506,6 +506,49 @@ def test_attn_decode_group(dev, B, G, Hq, Hkv, P, own, pad, nsp):
     # the ungrouped kernel on the fanned-out cache gives the same answer to within the split-order rounding
     std = ops.attn_decode(q.to(dev), k_true.to(dev), v_true.to(dev), pads.to(dev), ctx, max(1, min(16, ctx // 128)), D ** -0.5).cpu()
     close_bf16(out, std, ulps=3, atol=4e-3)
+    # shared prompt entries: the prompts' K/V kept ONCE ([B/G, Hkv, P + 3, D]), the rows' caches hold only their own keys from
+    # slot 0 -- bit-identical to the per-row-copy layout (same kernels, other addresses)
+    cap = P + 3
+    kpre = torch.full((B // G, Hkv, cap, D), 50.0).to(BF)
+    vpre = torch.full((B // G, Hkv, cap, D), -50.0).to(BF)
+    kpre[:, :, :P], vpre[:, :, :P] = kp, vp
+    k_own = k_true[:, :, P:].contiguous()
+    v_own = v_true[:, :, P:].contiguous()
+    out2 = ops.attn_decode_group_prefix(q.to(dev), k_own.to(dev), v_own.to(dev), kpre.to(dev), vpre.to(dev), G, pads.to(dev), G, P, ctx,
+                                        nsp, D ** -0.5).cpu()
+    assert torch.equal(out2, out)
+    if G % 2 == 0 and nsp > 0:      # sub-groups of G/2 rows inside a prompt's G rows
+        sub = ops.attn_decode_group_prefix(q.to(dev), k_own.to(dev), v_own.to(dev), kpre.to(dev), vpre.to(dev), G, pads.to(dev), G // 2, P,
+                                           ctx, nsp, D ** -0.5).cpu() if G // 2 > 1 else out2
+        close_bf16(sub, out, ulps=3, atol=4e-3)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,G,P,L,pad,rpt", [(128, 8, 2, 3, 200, 70, 0, 128), (128, 4, 4, 2, 129, 300, 5, 128), (32, 4, 2, 4, 77, 40, 0, 128),
+                                                    (64, 4, 2, 2, 64, 64, 3, 64)])
+def test_attn_tiles_prefix_equals_copied_prompt(dev, D, Hq, Hkv, G, P, L, pad, rpt):
+    """o3v_attn_tiles_prefix (the G completions' L tokens behind ONE copy of the prompt's P keys) == o3v_attn_tiles on caches that
+    each hold a copy of the prompt, bit for bit: causal tiles with past = P, left padding inside the prompt."""
+    import kernel_ops as ops
+    from open_o3_video_amd import indexing
+    g = torch.Generator().manual_seed(D + P + L)
+    q = torch.randn(G * L, Hq, D, generator=g).to(BF).to(dev)
+    kp = torch.randn(1, Hkv, P + 2, D, generator=g).to(BF)
+    vp = torch.randn(1, Hkv, P + 2, D, generator=g).to(BF)
+    ko = torch.randn(G, Hkv, L, D, generator=g).to(BF)
+    vo = torch.randn(G, Hkv, L, D, generator=g).to(BF)
+    kfull = torch.cat([kp[:, :, :P].expand(G, -1, -1, -1), ko], dim=2).contiguous()
+    vfull = torch.cat([vp[:, :, :P].expand(G, -1, -1, -1), vo], dim=2).contiguous()
+    tiles = torch.from_numpy(indexing.prefill_tiles(G, L, [pad] * G, tile=rpt, past=P)).to(dev)
+    QD = Hq * D
+    T1, T2 = P + L, L
+    a = torch.zeros(G * L, QD, dtype=BF, device=dev)
+    b = torch.zeros_like(a)
+    ops.attn_tiles(q, kfull.to(dev), vfull.to(dev), tiles, Hq, Hq // Hkv, D, QD, D, T1 * D, Hkv * T1 * D, D, T1 * D, Hkv * T1 * D, a, QD,
+                   D ** -0.5, rows_per_tile=rpt)
+    ops.attn_tiles_prefix(q, ko.to(dev), vo.to(dev), kp.to(dev), vp.to(dev), (P + 2) * D, Hkv * (P + 2) * D, P, G, tiles, Hq, Hq // Hkv, D,
+                          QD, D, T2 * D, Hkv * T2 * D, D, T2 * D, Hkv * T2 * D, b, QD, D ** -0.5, rows_per_tile=rpt)
+    assert torch.equal(a, b)
+    assert a.float().abs().sum().item() > 0
 
 
 def test_patchify_matches_hf_processor(dev, golden_dir):

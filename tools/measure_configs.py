@@ -34,7 +34,7 @@ def run(tag, frames_n, H, W, S_target, T, **kw):
     dt = time.perf_counter() - t0
     rows = out.sequences.shape[0]
     print(json.dumps({"config": tag, "S": len(ids), "rows": rows, "new_tokens": T, "wall_s": round(dt, 3),
-                      "tokens_per_s": round(rows * T / dt, 1), "stage_ms": {k: round(v, 1) for k, v in out.timings.items()},
+                      "tokens_per_s": round(rows * T / dt, 1), "stage_ms": {k: round(v, 1) for k, v in out.timings.items() if k.endswith("_ms")}, "kv_cache_GB": round(out.timings.get("kv_cache_bytes", 0) / 1e9, 3),
                       "decode_ms_per_step": round(out.timings["decode_ms"] / T, 3)}), flush=True)
 
 
@@ -200,7 +200,7 @@ if "q3" in which:
             rows = out.sequences.shape[0]
             print(json.dumps({"config": f"Qwen3-VL-8B dims, {NF}x{H}x{W}, {tag}, {'fp8' if fp8 else 'bf16'} decode rows", "S": len(ids),
                               "rows": rows, "new_tokens": T, "wall_s": round(dt, 3), "tokens_per_s": round(rows * T / dt, 1),
-                              "stage_ms": {k: round(v, 1) for k, v in out.timings.items()},
+                              "stage_ms": {k: round(v, 1) for k, v in out.timings.items() if k.endswith("_ms")}, "kv_cache_GB": round(out.timings.get("kv_cache_bytes", 0) / 1e9, 3),
                               "decode_ms_per_step": round(out.timings["decode_ms"] / T, 3),
                               "weights_GB": round(eng.w.nbytes() / 1e9, 2)}), flush=True)
         del eng
