@@ -26,7 +26,7 @@ typedef struct ihipStream_t* o3v_stream_t; /* hipStream_t */
 
 #define O3V_OK 0
 #define O3V_ERR_ARG (-1)    /* null pointer / negative size / inconsistent arguments */
-#define O3V_ERR_SHAPE (-2)  /* shape not supported by the kernels (alignment, head_dim, M > 16 for the decode linears ...) */
+#define O3V_ERR_SHAPE (-2)  /* shape not supported by the kernels (alignment, head_dim, M > 32 for the decode linears ...) */
 #define O3V_ERR_LAUNCH (-3) /* HIP reported a launch failure */
 #define O3V_ERR_WORKSPACE (-4)
 
@@ -107,8 +107,9 @@ int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias, const voi
 int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                          int lda, int ldw, int ldo, int ldr, int epilogue, int splits, float* workspace, size_t ws_bytes,
                          o3v_stream_t stream);
-/* same contract for M <= 16 rows (decode): weight-streaming GEMV up to 3 rows, matrix-core skinny GEMM from 4 rows on
- * (9..16 rows need K % 32 == 0 and N % 16 == 0). */
+/* same contract for M <= 32 rows (decode): weight-streaming GEMV up to 3 rows, matrix-core skinny GEMM from 4 rows on
+ * (9..32 rows need K % 32 == 0 and N % 16 == 0; 17..32 rows run two 16-row column blocks per streamed weight fragment and
+ * take no fused norm: normalise with o3v_rmsnorm first). */
 int o3v_gemv_bf16(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int ldx,
                   int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 

@@ -319,7 +319,7 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
                             o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
-    if (rows >= 8 && rows <= 16 && d->lm_head_p) {  // batched decode: norm apart, LDS-free matrix-core linear
+    if (rows >= 8 && rows <= 32 && d->lm_head_p) {  // batched decode: norm apart, LDS-free matrix-core linear
         TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
         return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
                                  d->vocab, 0, O3V_EPI_NONE, s);
@@ -349,7 +349,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     const int B = st->B;
     // shared prompt entries: the caches hold only the generated tokens (slot = step), the prompt K/V live once per prompt
     const bool pfx = st->kprefix != nullptr;
-    if (B <= 0 || B > 16 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew ||
+    if (B <= 0 || B > 32 || step0 < 0 || n_steps < 0 || step0 + n_steps > st->Tnew ||
         (pfx ? st->Tnew : st->S + st->Tnew) > st->Tmax + 1)
         return O3V_ERR_ARG;
     if (pfx && (!st->vprefix || st->group <= 1 || st->rows_per_prompt <= 0 || (B % st->rows_per_prompt) || st->S > st->prefix_cap))

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Skinny GEMM on the matrix cores for 2 <= M <= 16 rows (group rollout: G completions decode together).  The
+// Skinny GEMM on the matrix cores for 2 <= M <= 32 rows (group rollout: G completions decode together).  The
 // scalar GEMV above is VALU/LDS-bound beyond M ~ 2 (M*R dot products per weight chunk); here one
 // v_mfma_f32_16x16x32_bf16 multiplies 16 weight rows x 32 k against all M rows of x at once:
 //   A = W[16 rows][32 k]  (lane (row = lane&15, g = lane>>4) loads 16 B at W[row][k0 + 8g], straight from global)
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(const bf16_t* __rest
 // blocks j and j + D/2), the 4 waves of a block either take 4 different row groups (KS = 1) or split K (KS = 4).
 // NORM: RMSNorm of x fused, normalised rows kept in LDS with a 16-byte row skew (conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8>
+// CB: 16-row column blocks of x (M <= 16 * CB): every weight fragment feeds CB MFMAs, so 17..32 rows still stream the weights once.
+template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8, int CB = 1>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
@@ -441,9 +442,10 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     s_end = s_end < nks ? s_end : nks;
 
     // ---- epilogue operands of this lane (C[n = rb0 + 4*fg + r][m = fr]): requested now, a kernel's length ahead of their use
-    float e_bias[RB][4], e_res[4], e_cos[4], e_sin[4];
-    {
-        const int m = fr < M ? fr : 0;
+    float e_bias[RB][4], e_res[CB][4], e_cos[CB][4], e_sin[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int m = fr + 16 * cb < M ? fr + 16 * cb : 0;
 #pragma unroll
         for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -456,25 +458,26 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         for (int r = 0; r < 4; ++r) {
             int n = rb0[0] + fg * 4 + r;
             n = n < N ? n : N - 1;
-            e_res[r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
+            e_res[cb][r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
             if (EPI == EPI_QKVROPE) {
                 const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + (rb0[0] < N ? rb0[0] : 0) % ra.D + fg * 4 + r;
-                e_cos[r] = bf2f(ra.cosT[cs]);
-                e_sin[r] = bf2f(ra.sinT[cs]);
+                e_cos[cb][r] = bf2f(ra.cosT[cs]);
+                e_sin[cb][r] = bf2f(ra.sinT[cs]);
             } else {
-                e_cos[r] = e_sin[r] = 0.f;
+                e_cos[cb][r] = e_sin[cb][r] = 0.f;
             }
         }
     }
     // ---- weight stream, double buffered: two trips of U k-steps (UT KiB each) are in flight per wave, and the first one
     // is issued BEFORE the RMSNorm prologue so the HBM latency of the first weights hides the norm
-    f32x4 acc[RB];
+    f32x4 acc[RB][CB];
 #pragma unroll
-    for (int b = 0; b < RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool has_x = fr < M;
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[b][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int U = UT / RB;
-    bf16x8 wf0[U][RB], wf1[U][RB], xf0[U], xf1[U];
-    auto load_w = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U], int s0) {
+    bf16x8 wf0[U][RB], wf1[U][RB], xf0[U][CB], xf1[U][CB];
+    auto load_w = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U][CB], int s0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int sidx = s0 + u;
@@ -483,29 +486,41 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int b = 0; b < RB; ++b)
                     wf[u][b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow[b] + (PACKED ? (size_t)sidx * 512 : (size_t)kk)));
-                if (!NORM)
-                    xf[u] = has_x ? *reinterpret_cast<const bf16x8*>(X + (size_t)fr * ldx + kk + fg * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (!NORM) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        xf[u][cb] = fr + 16 * cb < M ? *reinterpret_cast<const bf16x8*>(X + (size_t)(fr + 16 * cb) * ldx + kk + fg * 8)
+                                                     : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
             } else {
 #pragma unroll
                 for (int b = 0; b < RB; ++b) wf[u][b] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (!NORM) xf[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (!NORM) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) xf[u][cb] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
         }
     };
-    auto compute = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U], int s0) {
+    auto compute = [&](bf16x8 (&wf)[U][RB], bf16x8 (&xf)[U][CB], int s0) {
         if (NORM) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int sidx = s0 + u;
                 const int kk = (sidx < s_end ? sidx : s_begin) * 32;  // past the end the weights are zero: any finite x will do
-                xf[u] = has_x ? *reinterpret_cast<const bf16x8*>(smem + (size_t)fr * xstride + (size_t)(kk + fg * 8) * 2)
-                              : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    xf[u][cb] = fr + 16 * cb < M
+                                    ? *reinterpret_cast<const bf16x8*>(smem + (size_t)(fr + 16 * cb) * xstride + (size_t)(kk + fg * 8) * 2)
+                                    : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int b = 0; b < RB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][b], xf[u], acc[b], 0, 0, 0);
+            for (int b = 0; b < RB; ++b)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][b], xf[u][cb], acc[b][cb], 0, 0, 0);
     };
     load_w(wf0, xf0, s_begin);
 
@@ -568,20 +583,26 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     if (KS > 1) {
         f32x4* part = reinterpret_cast<f32x4*>(smem + norm_bytes);
 #pragma unroll
-        for (int b = 0; b < RB; ++b) part[(wave * RB + b) * 64 + lane] = acc[b];
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) part[((wave * RB + b) * CB + cb) * 64 + lane] = acc[b][cb];
         __syncthreads();
         if (ks != 0) return;
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < RB; ++b)
 #pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) t += part[((rg * KS + k2) * RB + b) * 64 + lane];
-            acc[b] = t;
-        }
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k2 = 0; k2 < KS; ++k2) t += part[(((rg * KS + k2) * RB + b) * CB + cb) * 64 + lane];
+                acc[b][cb] = t;
+            }
     }
-    // ---- epilogue: this lane holds C[n = rb0 + 4*fg + r][m = fr]
-    const int m = fr;
-    if (m >= M) return;
+    // ---- epilogue: this lane holds C[n = rb0 + 4*fg + r][m = fr + 16 cb]
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+    const int m = fr + 16 * cb;
+    if (m >= M) continue;
     if (EPI == EPI_SWIGLU) {
         const int no0 = grp * 16 + fg * 4;
 #pragma unroll
@@ -589,24 +610,24 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
             const int no = no0 + r;
             if (no >= (N >> 1)) continue;
             const float bg = e_bias[0][r], bu = e_bias[RB - 1][r];
-            const float g = rbf(acc[0][r] + bg), u = rbf(acc[RB - 1][r] + bu);
+            const float g = rbf(acc[0][cb][r] + bg), u = rbf(acc[RB - 1][cb][r] + bu);
             out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
         }
     } else if (EPI == EPI_QKVROPE) {
         const int half = ra.D >> 1, head = rb0[0] / ra.D, j0 = rb0[0] % ra.D + fg * 4;
-        if (rb0[0] >= N) return;
+        if (rb0[0] >= N) return;  // block-uniform
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + r;
             const float b0 = e_bias[0][r], b1 = e_bias[RB - 1][r];
-            const float v0 = rbf(acc[0][r] + b0), v1 = rbf(acc[RB - 1][r] + b1);
+            const float v0 = rbf(acc[0][cb][r] + b0), v1 = rbf(acc[RB - 1][cb][r] + b1);
             if (head >= ra.Hq + ra.Hkv) {
                 bf16_t* dst = ra.vc + (((size_t)m * ra.Hkv + (head - ra.Hq - ra.Hkv)) * ra.Tmax + ra.slot) * ra.D;
                 dst[j] = f2bf(v0);
                 dst[j + half] = f2bf(v1);
                 continue;
             }
-            const float c = e_cos[r], sn = e_sin[r];
+            const float c = e_cos[cb][r], sn = e_sin[cb][r];
             const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
             const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
             bf16_t* dst = head < ra.Hq ? ra.qout + ((size_t)m * ra.Hq + head) * ra.D
@@ -619,12 +640,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         for (int r = 0; r < 4; ++r) {
             const int n = rb0[0] + fg * 4 + r;
             if (n >= N) continue;
-            float v = acc[0][r] + e_bias[0][r];
-            if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[r];
+            float v = acc[0][cb][r] + e_bias[0][r];
+            if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[cb][r];
             if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
             if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
             out[(size_t)m * ldo + n] = f2bf(v);
         }
+    }
     }
 }
 
@@ -867,6 +889,7 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     constexpr int RG = 4 / KS;
     dim3 grid((groups + RG - 1) / RG), block(256);
     const size_t shmem = (NORM ? (size_t)M * (a.K * 2 + 16) : 0) + (KS > 1 ? (size_t)4 * RB * 64 * 16 : 0) + (NORM ? 16 * 4 * 4 : 0);
+    const size_t shmem2 = KS > 1 ? (size_t)4 * RB * 2 * 64 * 16 : 0;  // two column blocks of split-K partials
 #ifdef O3V_TUNE
     if (g_mt_ut == 16) {
         O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 16>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
@@ -887,6 +910,16 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     // 16 KiB of weight loads in flight per wave for the single-block epilogues, 8 KiB for the paired (gate/up, q/k/v) ones:
     // A/B on the 7B shapes in profiles/r01_m8_linear.txt
     constexpr int UT = RB == 1 ? 16 : 8;
+    if (M > 16) {
+        // 17..32 rows: two column blocks per weight fragment (x fragments from L2: no fused norm), half the weight bytes in flight
+        // per wave so that the doubled x fragments and accumulators fit the register file
+        if constexpr (!NORM) {
+            O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, 8, 2>), grid, block, shmem2, a.s, a.X, a.W, a.bias, a.res, a.out,
+                        a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+            return O3V_OK;
+        }
+        return O3V_ERR_SHAPE;
+    }
     O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, UT>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, a.eps,
                 M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
     return O3V_OK;
@@ -929,7 +962,7 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
                          hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr,
                          const float* wscale = nullptr) {
     if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
-    if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 16) return O3V_ERR_SHAPE;
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 32 || (M > 16 && norm_w)) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
     if (M == 0) return O3V_OK;
@@ -963,7 +996,7 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
         O3V_CHECK_LAUNCH();
         return O3V_OK;
     }
-    if (M > 8) return O3V_ERR_SHAPE;  // 9..16 rows exist only on the matrix-core path (one MFMA column block)
+    if (M > 8) return O3V_ERR_SHAPE;  // 9..32 rows exist only on the matrix-core path (one or two MFMA column blocks)
     a.W = (const bf16_t*)W;  // scalar path reads the row-major image
     a.packed = false;
     int rc;

@@ -43,7 +43,7 @@ class GenerateOutput:
 
 
 class O3VEngine:
-    MAX_ROWS = 16   # decode rows per call: the skinny MFMA GEMM multiplies 16 weight rows against up to 16 rows of x
+    MAX_ROWS = 32   # decode rows per call: the skinny MFMA GEMM multiplies 16 weight rows against one or two 16-row blocks of x
 
     def __init__(self, cfg: O3VConfig, weights: DeviceWeights):
         if not torch.cuda.is_available():
@@ -284,7 +284,7 @@ class O3VEngine:
         G = int(num_return_sequences)
         B = B0 * G
         if B > self.MAX_ROWS:
-            raise ValueError(f"at most {self.MAX_ROWS} sequences per engine call (one 16-column MFMA block in the decode linears); "
+            raise ValueError(f"at most {self.MAX_ROWS} sequences per engine call (two 16-column MFMA blocks in the decode linears); "
                              "shard larger batches")
         pad_id = cfg.pad_token_id if pad_token_id is None else int(pad_token_id)
         T = int(max_new_tokens)
@@ -375,7 +375,7 @@ class O3VEngine:
         # context splits of the decode attention: one 128-key chunk per block at 1-4 rows; from 8 rows on fewer, longer chunks
         # so that the grid stays near 640 blocks (measured, 7B: 8 rows 40 -> 20 splits 3.85 -> 3.72 ms/step; 16 independent rows
         # 32 -> 8 splits 2020 -> 2128 tok/s; 2 and 4 rows are best at 40)
-        nsplit = max(1, min(64, (Tmax + 127) // 128, max(1, 640 // max(1, B * tc.num_key_value_heads))))
+        nsplit = max(1, min(64, (S + T + 127) // 128, max(1, 640 // max(1, B * tc.num_key_value_heads))))
         # G completions of a prompt share its K/V: the group kernel reads the prompt keys once per group (head_dim 128,
         # G * n_rep <= 64 query rows per kv head, prefix splits + own-key splits <= 64)
         n_rep = tc.num_attention_heads // tc.num_key_value_heads

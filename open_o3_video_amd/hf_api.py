@@ -22,7 +22,7 @@ from .config import O3VConfig
 from .engine import O3VEngine
 from .weights import DeviceWeights, getter_from_dict, getter_from_safetensors_dir
 
-MAX_ROWS = 16  # sequences per engine call (O3VEngine.MAX_ROWS)
+MAX_ROWS = 32  # sequences per engine call (O3VEngine.MAX_ROWS)
 
 
 class GenerationConfigLike(SimpleNamespace):

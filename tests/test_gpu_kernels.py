@@ -297,6 +297,75 @@ def test_linear_decode_packed_weights(dev, M, N, K, epi_name, norm):
     close_bf16(outs[1], outs[0].float(), ulps=1, atol=1e-3, frac=0.999)
 
 
+@pytest.mark.parametrize("M", [17, 24, 32])
+@pytest.mark.parametrize("N,K,epi_name", [(4608, 3584, "none"), (37888, 3584, "swiglu"), (3584, 18944, "res"), (3584, 3584, "res"),
+                                          (512, 128, "gelu"), (2304, 896, "swiglu"), (8192, 1024, "none")])
+def test_linear_decode_two_column_blocks(dev, M, N, K, epi_name):
+    """17..32 decode rows: two 16-row column blocks of x per streamed weight fragment (gemv_mfma_kernel<CB = 2>, x already
+    normalised) -- against the fp32 reference, and rows 0..15 against the one-block kernel on the same rows."""
+    import ctypes as C
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    g = torch.Generator().manual_seed(M * 5 + N)
+    x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wp = pack_mfma_fragments(w)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    epi = {"none": ops.EPI_NONE, "swiglu": ops.EPI_SWIGLU, "res": ops.EPI_RESIDUAL, "gelu": ops.EPI_GELU}[epi_name]
+    No = N // 2 if epi == ops.EPI_SWIGLU else N
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty(M, No, dtype=BF, device=dev)
+    _lib.call("o3v_linear_decode", P(x), None, 0.0, P(w), P(wp), P(bias), P(res) if epi == ops.EPI_RESIDUAL else None, P(out), M, N, K, K,
+              No, N, epi, st)
+    if epi == ops.EPI_SWIGLU:
+        ref = ops.gemm(x, w, bias, None, epi, force="gemm")
+        close_bf16(out, ref.float(), ulps=1, atol=1e-3, frac=0.999)
+    else:
+        close_bf16(out, _epi_ref(x.float() @ w.float().t(), bias, res if epi == ops.EPI_RESIDUAL else None, epi))
+    out16 = torch.empty(16, No, dtype=BF, device=dev)
+    _lib.call("o3v_linear_decode", P(x), None, 0.0, P(w), P(wp), P(bias), P(res) if epi == ops.EPI_RESIDUAL else None, P(out16), 16, N, K,
+              K, No, N, epi, st)
+    close_bf16(out[:16], out16.float(), ulps=1, atol=1e-3, frac=0.999)
+    # a fused norm is not offered above 16 rows (the normalised rows would not fit in LDS): the engine runs the norm apart
+    nw = torch.ones(K, dtype=BF, device=dev)
+    assert _lib.load().o3v_linear_decode(P(x), P(nw), 1e-6, P(w), P(wp), P(bias), None, P(out), M, N, K, K, No, N, ops.EPI_NONE, st) == _lib.ERR_SHAPE
+
+
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(32, 28, 4, 128, 3584), (19, 8, 2, 128, 1024), (24, 4, 2, 32, 128)])
+def test_qkv_rope_cache_two_column_blocks(dev, M, Hq, Hkv, D, K):
+    """Decode q/k/v (+bias, M-RoPE, cache append) at 17..32 rows on already normalised x == GEMM -> o3v_qkv_rope_cache."""
+    import ctypes as C
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    g = torch.Generator().manual_seed(M + Hq)
+    N, Tmax, Tnew, step, slot = (Hq + 2 * Hkv) * D, 40, 6, 4, 33
+    x = (torch.randn(M, K, generator=g)).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wp = pack_mfma_fragments(w)
+    bias = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    ang = torch.rand(M, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    qkv = ops.gemm(x, w, bias, None, ops.EPI_NONE, force="gemm")
+    q1 = torch.zeros(M, Hq, D, dtype=BF, device=dev)
+    k1 = torch.zeros(M, Hkv, Tmax, D, dtype=BF, device=dev)
+    v1 = torch.zeros_like(k1)
+    _lib.call("o3v_qkv_rope_cache", P(qkv), P(cos), P(sin), P(q1), P(k1), P(v1), slot, M, 1, Hq, Hkv, D, Tmax, Tnew, step, st)
+    q2, k2, v2 = torch.zeros_like(q1), torch.zeros_like(k1), torch.zeros_like(v1)
+    _lib.call("o3v_gemv_norm_qkv_rope", P(x), None, 0.0, P(w), P(wp), P(bias), M, K, K, P(cos), P(sin), P(q2), P(k2), P(v2), slot, Hq,
+              Hkv, D, Tmax, Tnew, step, st)
+    close_bf16(q2, q1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(k2, k1.float(), ulps=1, atol=2e-3, frac=0.999)
+    close_bf16(v2, v1.float(), ulps=1, atol=2e-3, frac=0.999)
+    assert (k2[:, :, :slot] == 0).all() and (k2[:, :, slot + 1:] == 0).all()
+
+
 def test_gemm_rejects_bad_shapes(dev):
     import kernel_ops as ops
     from open_o3_video_amd import _lib

@@ -320,7 +320,16 @@ def test_generate_edge_cases(need_gpu):
                        steps_per_sync=1)
     assert out.n_steps == 1 and np.array_equal(out.sequences.cpu().numpy()[:, L], first)
     with pytest.raises(ValueError):
-        eng.generate([[1, 2]] * 17, None, max_new_tokens=1)                 # more rows than one engine call takes
+        eng.generate([[1, 2]] * 33, None, max_new_tokens=1)                 # more rows than one engine call takes
+    # 17..32 rows: the decode linears run two 16-row column blocks per weight fragment
+    many = [[3 + i, 40 + 2 * i, 7, 9 + i] for i in range(21)]
+    wide = eng.generate(many, None, max_new_tokens=5).sequences.cpu().numpy()
+    for i in (0, 15, 16, 20):
+        solo = eng.generate([many[i]], None, max_new_tokens=5)
+        k = 0
+        while k < 5 and wide[i, 4 + k] == solo.sequences[0, 4 + k].item():
+            k += 1
+        assert k == 5 or solo.margins[0, k].item() < 2 * LOGIT_ATOL, (i, k)
     with pytest.raises(ValueError):
         eng.generate([ids], None, frames=fr[:1], max_new_tokens=1)          # fewer frames than image placeholders
 
