@@ -203,6 +203,15 @@ int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, const void* 
                               void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv,
                               int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
                               uint32_t epoch, o3v_stream_t stream);
+/* Qwen3-VL form (TF3:438-500): no q/k/v bias; RMSNorm weights q_norm / k_norm bf16 [D] on every q and k head between the
+ * projection and the rotation.  kv_raw: (Hq + 2 * Hkv) * D bf16 of scratch.  qkv_s / o_s NULL: bf16 rows; non-NULL: fp8 rows + scales.
+ * Bit-identical to o3v_linear_decode (q/k/v) + o3v_qkv_norm_rope_cache + o3v_attn_decode + o3v_linear_decode (o_proj, RESIDUAL). */
+int o3v_decode_attn_block_qknorm(void* x, const void* ln_w, float eps, const void* qkv_w, const float* qkv_s, const void* o_w,
+                                 const float* o_s, const void* q_norm, const void* k_norm, void* kv_raw, const void* cosT,
+                                 const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache, float* part_o,
+                                 float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax,
+                                 int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
+                                 o3v_stream_t stream);
 
 /* ---- sampling / log-probs ------------------------------------------------------------------------------------ */
 /* GenerationMixin._sample greedy branch + RepetitionPenaltyLogitsProcessor,

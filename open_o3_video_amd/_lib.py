@@ -100,6 +100,8 @@ SIGNATURES = {
     "o3v_decode_attn_block_capacity": [i32, i32],
     "o3v_decode_attn_block_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                   i32, i32, i32, f32, vp, C.c_uint32, vp],
+    "o3v_decode_attn_block_qknorm": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
+                                     i32, i32, i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_decode_attn_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                               i32, f32, vp, C.c_uint32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],

@@ -99,6 +99,79 @@ struct PrefixRef {
     int rows;     // decode rows per prompt: row b reads prompt b / rows
 };
 
+// Qwen3-VL (TF3:480-484) inside the one-launch block: the q/k/v role publishes the projection outputs un-normalised and
+// un-rotated (q_raw, k_raw, v_raw); the q/k/v workgroup that takes a kv head's LAST ticket then finishes that head group -- its
+// n_rep q heads and the new key's k row normalised + rotated, the v row copied -- and only then tells the mailboxes, so the
+// attention and o_proj roles run unchanged.  Same arithmetic as o3v_qkv_norm_rope_cache (qkn_* / rope_share).
+struct QkNormRef {
+    const bf16_t *q_raw, *k_raw, *v_raw;  // [Hq, D], [Hkv, D], [Hkv, D]
+    const bf16_t *q_norm, *k_norm;        // [D]
+    const bf16_t *cosr, *sinr;            // rotary row of this token, [D]
+    float eps;
+};
+
+// One head per 16-lane row in the MFMA operand layout: the four lanes fg = 0..3 hold x[ks] = dims 32 ks + 8 fg .. +7, i.e. the lane
+// shares fg = (x[0], x[2]) and 4 + fg = (x[1], x[3]).  The eight share sums are added pairwise over share distance 1, 2, 4 exactly
+// as o3v_qkv_norm_rope_cache adds them; then w * bf16(x * rstd) and the rotation.
+__device__ __forceinline__ void qkn_norm_rope_mfma(u32x4 (&x)[4], const bf16_t* nw, const QkNormRef& qk, const int fg) {
+    float s_lo = qkn_chain(x[0], x[2]), s_hi = qkn_chain(x[1], x[3]);
+    s_lo += __shfl_xor(s_lo, 16, 64);
+    s_hi += __shfl_xor(s_hi, 16, 64);
+    s_lo += __shfl_xor(s_lo, 32, 64);
+    s_hi += __shfl_xor(s_hi, 32, 64);
+    const float rstd = qkn_rstd(s_lo + s_hi, 128, qk.eps);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) x[ks] = qkn_scale(x[ks], *reinterpret_cast<const u32x4*>(nw + ks * 32 + fg * 8), rstd);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        u32x4 ol, oh;
+        rope_share(x[p], x[p + 2], *reinterpret_cast<const u32x4*>(qk.cosr + p * 32 + fg * 8),
+                   *reinterpret_cast<const u32x4*>(qk.sinr + p * 32 + fg * 8), ol, oh);
+        x[p] = ol;
+        x[p + 2] = oh;
+    }
+}
+
+// Head group g finished by ONE wave (all 64 lanes active): rows fr < n_rep of the lane grid are the group's q heads, then row 0
+// is its k head; v is copied by lanes 0..15.  Everything is read past L1, written through and drained before the return.
+__device__ __forceinline__ void qkn_finish_head_group(const QkNormRef& qk, const int g, const int n_rep, bf16_t* q_out, bf16_t* krow,
+                                                      bf16_t* vrow) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t qr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(qk.q_raw + (size_t)g * n_rep * 128), 0, n_rep * 128 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(qk.k_raw + (size_t)g * 128), 0, 128 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)(qk.v_raw + (size_t)g * 128), 0, 128 * 2, 0x00020000);
+    u32x4 xq[4], xk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // rows past the descriptors read zeros
+        xq[ks] = load16_sc1(qr, (uint32_t)(fr * 128 + ks * 32 + fg * 8) * 2);
+        xk[ks] = load16_sc1(kr, fr == 0 ? (uint32_t)(ks * 32 + fg * 8) * 2 : O3V_OOB);
+    }
+    const u32x4 tv = load16_sc1(vr, lane < 16 ? (uint32_t)lane * 16 : O3V_OOB);
+    qkn_norm_rope_mfma(xq, qk.q_norm, qk, fg);
+    qkn_norm_rope_mfma(xk, qk.k_norm, qk, fg);
+    if (fr < n_rep) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(q_out + ((size_t)g * n_rep + fr) * 128);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __hip_atomic_store(dst + (ks * 32 + fg * 8) / 2 + j, xq[ks][j], O3V_RLX_AGENT);
+    }
+    if (fr == 0) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(krow);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __hip_atomic_store(dst + (ks * 32 + fg * 8) / 2 + j, xk[ks][j], O3V_RLX_AGENT);
+    }
+    if (lane < 16) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(vrow) + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __hip_atomic_store(dst + j, tv[j], O3V_RLX_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <bool FUSED>
 __device__ __forceinline__ void attn_decode_mfma_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kc,
                                                       const bf16_t* __restrict__ Vc, float* __restrict__ part_o,

@@ -41,6 +41,41 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- per-head q/k RMSNorm + rotation (Qwen3-VL, TF3:480-484), shared by o3v_qkv_norm_rope_cache and the one-launch decode block
+// so that both round identically.  A "lane share" of a head is an 8-wide chunk of each rotary half (lo: dims 8c.., hi: D/2 + 8c..).
+__device__ __forceinline__ float qkn_chain(const u32x4& lo, const u32x4& hi) {  // sum of squares of a lane share, fixed order
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ss = fmaf(bf_lo(lo[j]), bf_lo(lo[j]), ss);
+        ss = fmaf(bf_hi(lo[j]), bf_hi(lo[j]), ss);
+        ss = fmaf(bf_lo(hi[j]), bf_lo(hi[j]), ss);
+        ss = fmaf(bf_hi(hi[j]), bf_hi(hi[j]), ss);
+    }
+    return ss;
+}
+__device__ __forceinline__ float qkn_rstd(float ss, int D, float eps) { return 1.0f / sqrtf(ss / (float)D + eps); }
+__device__ __forceinline__ u32x4 qkn_scale(const u32x4& x, const u32x4& w, float rstd) {  // w * bf16(x * rstd), rounded to bf16
+    u32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = pack_bf2(bf_lo(w[j]) * rbf(bf_lo(x[j]) * rstd), bf_hi(w[j]) * rbf(bf_hi(x[j]) * rstd));
+    return y;
+}
+// rotate a lane share: out_lo = bf16(bf16(lo*cos) + bf16(-hi*sin)), out_hi = bf16(bf16(hi*cos) + bf16(lo*sin))   (TF:598-599 in bf16)
+__device__ __forceinline__ void rope_share(const u32x4& lo, const u32x4& hi, const u32x4& cv, const u32x4& sv, u32x4& ol, u32x4& oh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = bf_lo(lo[j]), a1 = bf_hi(lo[j]), b0 = bf_lo(hi[j]), b1 = bf_hi(hi[j]);
+        const float c0 = bf_lo(cv[j]), c1 = bf_hi(cv[j]), s0 = bf_lo(sv[j]), s1 = bf_hi(sv[j]);
+        const float l0 = rbf(__fadd_rn(rbf(__fmul_rn(a0, c0)), rbf(__fmul_rn(-b0, s0))));
+        const float l1 = rbf(__fadd_rn(rbf(__fmul_rn(a1, c1)), rbf(__fmul_rn(-b1, s1))));
+        const float h0 = rbf(__fadd_rn(rbf(__fmul_rn(b0, c0)), rbf(__fmul_rn(a0, s0))));
+        const float h1 = rbf(__fadd_rn(rbf(__fmul_rn(b1, c1)), rbf(__fmul_rn(a1, s1))));
+        ol[j] = pack_bf2(l0, l1);
+        oh[j] = pack_bf2(h0, h1);
+    }
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // F.gelu(approximate="tanh") in fp32 (ATen's GeluKernel: kBeta = sqrt(2/pi), kKappa = 0.044715)

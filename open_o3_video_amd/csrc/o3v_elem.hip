@@ -280,35 +280,18 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(const bf16_t* __res
         const int tin = t - b * tokens_per_row;
         const int slot = slot_base + tin;
         const bf16_t* src = qkv + (size_t)t * HT * D + (size_t)h * D + c * 8;
-        uint4 lo = *reinterpret_cast<const uint4*>(src);
-        uint4 hi = *reinterpret_cast<const uint4*>(src + half);
+        u32x4 lo = *reinterpret_cast<const u32x4*>(src);
+        u32x4 hi = *reinterpret_cast<const u32x4*>(src + half);
         if (QKNORM) {
-            // every lane of the head's group takes part (v heads too: their sum is simply not used)
-            const uint32_t* xl = reinterpret_cast<const uint32_t*>(&lo);
-            const uint32_t* xh = reinterpret_cast<const uint32_t*>(&hi);
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ss = fmaf(bf_lo(xl[j]), bf_lo(xl[j]), ss);
-                ss = fmaf(bf_hi(xl[j]), bf_hi(xl[j]), ss);
-                ss = fmaf(bf_lo(xh[j]), bf_lo(xh[j]), ss);
-                ss = fmaf(bf_hi(xh[j]), bf_hi(xh[j]), ss);
-            }
+            // every lane of the head's group takes part (v heads too: their sum is simply not used).  Lane shares are summed
+            // pairwise over lane distance 1, 2, 4: ((S0+S1)+(S2+S3)) + ((S4+S5)+(S6+S7)) at D = 128, in every lane
+            float ss = qkn_chain(lo, hi);
             for (int m = 1; m < cpr; m <<= 1) ss += __shfl_xor(ss, m, 64);
             if (h < Hq + Hkv) {
-                const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+                const float rstd = qkn_rstd(ss, D, eps);
                 const bf16_t* nw = (h < Hq ? q_norm : k_norm) + c * 8;
-                const uint4 wl = *reinterpret_cast<const uint4*>(nw);
-                const uint4 wh = *reinterpret_cast<const uint4*>(nw + half);
-                const uint32_t* pwl = reinterpret_cast<const uint32_t*>(&wl);
-                const uint32_t* pwh = reinterpret_cast<const uint32_t*>(&wh);
-                uint32_t* yl = reinterpret_cast<uint32_t*>(&lo);
-                uint32_t* yh = reinterpret_cast<uint32_t*>(&hi);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    yl[j] = pack_bf2(bf_lo(pwl[j]) * rbf(bf_lo(xl[j]) * rstd), bf_hi(pwl[j]) * rbf(bf_hi(xl[j]) * rstd));
-                    yh[j] = pack_bf2(bf_lo(pwh[j]) * rbf(bf_lo(xh[j]) * rstd), bf_hi(pwh[j]) * rbf(bf_hi(xh[j]) * rstd));
-                }
+                lo = qkn_scale(lo, *reinterpret_cast<const u32x4*>(nw), rstd);
+                hi = qkn_scale(hi, *reinterpret_cast<const u32x4*>(nw + half), rstd);
             }
         }
         bf16_t* dst;
@@ -318,34 +301,16 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(const bf16_t* __res
             dst = kc + (((size_t)b * Hkv + (h - Hq)) * Tmax + slot) * D + c * 8;
         } else {
             dst = vc + (((size_t)b * Hkv + (h - Hq - Hkv)) * Tmax + slot) * D + c * 8;
-            *reinterpret_cast<uint4*>(dst) = lo;
-            *reinterpret_cast<uint4*>(dst + half) = hi;
+            *reinterpret_cast<u32x4*>(dst) = lo;
+            *reinterpret_cast<u32x4*>(dst + half) = hi;
             continue;
         }
         // cos/sin row: row-major [rows, D]; both halves hold the same value so read the first half only
         size_t csr = (size_t)(b * cs_stride_row + cs_off + tin) * D + c * 8;
-        uint4 cv = *reinterpret_cast<const uint4*>(cosT + csr);
-        uint4 sv = *reinterpret_cast<const uint4*>(sinT + csr);
-        const uint32_t* pl = reinterpret_cast<const uint32_t*>(&lo);
-        const uint32_t* ph = reinterpret_cast<const uint32_t*>(&hi);
-        const uint32_t* pc = reinterpret_cast<const uint32_t*>(&cv);
-        const uint32_t* ps = reinterpret_cast<const uint32_t*>(&sv);
-        uint4 ol, oh;
-        uint32_t* pol = reinterpret_cast<uint32_t*>(&ol);
-        uint32_t* poh = reinterpret_cast<uint32_t*>(&oh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a0 = bf_lo(pl[j]), a1 = bf_hi(pl[j]), b0 = bf_lo(ph[j]), b1 = bf_hi(ph[j]);
-            float c0 = bf_lo(pc[j]), c1 = bf_hi(pc[j]), s0 = bf_lo(ps[j]), s1 = bf_hi(ps[j]);
-            float l0 = rbf(__fadd_rn(rbf(__fmul_rn(a0, c0)), rbf(__fmul_rn(-b0, s0))));
-            float l1 = rbf(__fadd_rn(rbf(__fmul_rn(a1, c1)), rbf(__fmul_rn(-b1, s1))));
-            float h0 = rbf(__fadd_rn(rbf(__fmul_rn(b0, c0)), rbf(__fmul_rn(a0, s0))));
-            float h1 = rbf(__fadd_rn(rbf(__fmul_rn(b1, c1)), rbf(__fmul_rn(a1, s1))));
-            pol[j] = pack_bf2(l0, l1);
-            poh[j] = pack_bf2(h0, h1);
-        }
-        *reinterpret_cast<uint4*>(dst) = ol;
-        *reinterpret_cast<uint4*>(dst + half) = oh;
+        u32x4 ol, oh;
+        rope_share(lo, hi, *reinterpret_cast<const u32x4*>(cosT + csr), *reinterpret_cast<const u32x4*>(sinT + csr), ol, oh);
+        *reinterpret_cast<u32x4*>(dst) = ol;
+        *reinterpret_cast<u32x4*>(dst + half) = oh;
     }
 }
 

@@ -373,7 +373,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
     const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
     const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
-    bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0 && !qk_norm;
+    bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
     int step = step0;
     // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
     auto attention_half = [&](int l) -> int {
@@ -435,7 +435,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             if (fused) {
                 const uint32_t epoch = (uint32_t)(step * d->layers + l + 1);
                 const int rc =
-                    fp8 ? o3v_decode_attn_block_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, lw.o_w8, lw.o_s, st->cosT,
+                    qk_norm ? o3v_decode_attn_block_qknorm(st->x, lw.ln1, d->rms_eps, fp8 ? lw.qkv_w8 : lw.qkv_w, fp8 ? lw.qkv_s : nullptr,
+                                                           fp8 ? lw.o_w8 : lw.o_w, fp8 ? lw.o_s : nullptr, lw.q_norm, lw.k_norm, w.qkv,
+                                                           st->cosT, st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq,
+                                                           Hkv, D, st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync,
+                                                           epoch, s)
+                    : fp8 ? o3v_decode_attn_block_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, lw.o_w8, lw.o_s, st->cosT,
                                                     st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D,
                                                     st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync, epoch, s)
                         : o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,

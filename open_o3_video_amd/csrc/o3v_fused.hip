@@ -45,7 +45,9 @@ struct FusedArgs {
     const int* k_lo;
     uint32_t* sync;
     uint32_t epoch;
-    RopeArgs ra;
+    RopeArgs ra;        // destinations and rotary row of this token (true cache geometry)
+    RopeArgs ra_qkv;    // what the q/k/v role writes through: == ra, or (QKN) the raw scratch with the rotation switched off
+    QkNormRef qk;       // QKN only
     float eps, scale_log2e;
     int H, ctx, nsplit, nb_qkv, nb_attn, nb_o;
 #ifdef O3V_STAMPS
@@ -146,7 +148,8 @@ __device__ __forceinline__ void oproj_role(const FusedArgs& a, const int bid) {
 // NSTEP: steps of 64 16-byte weight chunks of an o_proj row (K = Hq*D; 512 k per step in bf16, 1024 in fp8); WB: bytes per
 // weight of the two projections.  (Requesting a q/k/v row pair's whole weight stream in one trip was measured and dropped:
 // no faster, and 170+ VGPRs.)
-template <int NSTEP, int WB>
+// QKN: Qwen3-VL's per-head q/k RMSNorm sits between the projection and the rotation (QkNormRef in o3v_attn_decode_body.h)
+template <int NSTEP, int WB, bool QKN = false>
 __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
     O3V_STAMP(O3V_STAMP_PTR(a), 0);
     if (bid < a.nb_qkv) {
         gemv_body<1, 2, 1, EPI_QKVROPE, true, true, 0, 4, WB>(a.x, a.qkv_w, a.qkv_b, nullptr, nullptr, a.ln_w, a.eps,
-                                                              (Hq + 2 * Hkv) * D, a.H, a.H, a.H, 0, 0, a.ra, bid, smem, a.qkv_s);
+                                                              (Hq + 2 * Hkv) * D, a.H, a.H, a.H, 0, 0, a.ra_qkv, bid, smem, a.qkv_s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
         __syncthreads();
         if (threadIdx.x < 64) {  // wave 0: ticket; the last workgroup of the kv head tells that head's attention workgroups
@@ -164,6 +167,9 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
             if (threadIdx.x == 0) old = __hip_atomic_fetch_add(a.sync + SYNC_QKV + g * O3V_SYNC_STRIDE, 1u, O3V_RLX_AGENT);
             old = __builtin_amdgcn_readfirstlane(old);
             if (old == a.epoch * (uint32_t)((n_rep + 2) * (D >> 3)) - 1u) {
+                if (QKN)  // every raw q/k/v row of kv head g is in memory: finish the head group, then tell the consumers
+                    qkn_finish_head_group(a.qk, g, n_rep, a.ra.qout, a.ra.kc + ((size_t)g * a.ra.Tmax + a.ra.slot) * D,
+                                          a.ra.vc + ((size_t)g * a.ra.Tmax + a.ra.slot) * D);
                 notify_mailboxes(a.sync + SYNC_BOX_ATT + (size_t)g * a.nsplit * O3V_SYNC_STRIDE, a.nsplit, 0, a.epoch);
                 notify_mailboxes(a.sync + SYNC_BOX_O, a.nb_o, 8 + g, a.epoch);  // o_proj: "q/k/v of kv head g are done"
             }
@@ -199,12 +205,12 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
 }
 
 // workgroups of this kernel the chip holds at once (0: query failed)
-template <int NSTEP, int WB>
+template <int NSTEP, int WB, bool QKN = false>
 int fused_capacity(size_t shmem) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_block_kernel<NSTEP, WB>, 256, shmem) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_block_kernel<NSTEP, WB, QKN>, 256, shmem) != hipSuccess) return 0;
     // the query can over-report for SGPR-heavy kernels, never below 6 workgroups per CU (MI355X_MICROARCH.md, Residency)
     if (per_cu > 6) per_cu = 6;
     return per_cu * prop.multiProcessorCount;
@@ -215,6 +221,8 @@ int fused_capacity(size_t shmem) {
 // o_proj row lengths built (steps of 64 chunks): bf16 rows of 1792 (fixtures) / 2048 (3B) / 3584 (7B) / 4096 (8B class) take
 // 4 / 4 / 7 / 8 steps, their fp8 forms 2 / 2 / 4 / 4
 #define O3V_FUSED_SHAPES(X) X(7, 2) X(4, 2) X(8, 2) X(2, 1) X(4, 1)
+// with the q/k norm (Qwen3-VL): rows of 4096 (8B) and 1024 (fixture) in bf16 and fp8
+#define O3V_FUSED_SHAPES_QKN(X) X(8, 2) X(2, 2) X(4, 1) X(1, 1)
 
 // workgroups of the fused kernel the chip holds at once for o_proj rows of qd = Hq*D elements of wb bytes (diagnostics / tests)
 extern "C" int o3v_decode_attn_block_capacity(int qd, int wb) {
@@ -236,12 +244,15 @@ extern "C" void o3v_fused_set_knob(int k) { g_knob = k; }
 extern "C" size_t o3v_decode_sync_bytes(void) { return (size_t)SYNC_WORDS * 4; }
 
 static int attn_block_launch(void* x, const void* ln_w, float eps, const void* qkv_w, const float* qkv_s, const void* qkv_b,
-                             const void* o_w, const float* o_s, const void* cosT, const void* sinT, void* q_buf, void* att_buf,
+                             const void* o_w, const float* o_s, const void* q_norm, const void* k_norm, void* kv_raw,
+                             const void* cosT, const void* sinT, void* q_buf, void* att_buf,
                              void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv,
                              int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
                              uint32_t epoch, hipStream_t stream) {
     const int wb = qkv_s ? 1 : 2;
     if ((qkv_s == nullptr) != (o_s == nullptr)) return O3V_ERR_ARG;
+    const bool qkn = q_norm != nullptr;
+    if (qkn && (!k_norm || !kv_raw)) return O3V_ERR_ARG;
     if (!x || !ln_w || !qkv_w || !o_w || !cosT || !sinT || !q_buf || !att_buf || !kcache || !vcache || !part_o || !part_ml ||
         !sync || epoch == 0 || slot < 0 || slot >= Tmax || H <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || nsplit <= 0 || nsplit > 64)
         return O3V_ERR_ARG;
@@ -272,6 +283,19 @@ static int attn_block_launch(void* x, const void* ln_w, float eps, const void* q
     a.epoch = epoch;
     a.ra = RopeArgs{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)q_buf, (bf16_t*)kcache, (bf16_t*)vcache,
                     slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
+    a.ra_qkv = a.ra;
+    a.qk = QkNormRef{};
+    if (qkn) {
+        // the q/k/v role stores bf16(acc + bias) as it is (rotation off) into the scratch [k: Hkv*D | v: Hkv*D | q: Hq*D] (cache
+        // geometry "one slot per head"); the last arriver of a kv head finishes the head group into q_buf and the cache row
+        bf16_t* kr = (bf16_t*)kv_raw;
+        bf16_t* vr = kr + (size_t)Hkv * D;
+        bf16_t* qr = vr + (size_t)Hkv * D;
+        a.ra_qkv = RopeArgs{nullptr, nullptr, qr, kr, vr, 0, Hq, Hkv, D, 1, 0, 0, 1};
+        const bf16_t* cr = (const bf16_t*)cosT + (size_t)cs_off * D;
+        const bf16_t* sr = (const bf16_t*)sinT + (size_t)cs_off * D;
+        a.qk = QkNormRef{qr, kr, vr, (const bf16_t*)q_norm, (const bf16_t*)k_norm, cr, sr, eps};
+    }
     a.eps = eps;
     a.scale_log2e = scale * 1.4426950408889634f;
     a.H = H;
@@ -293,7 +317,20 @@ static int attn_block_launch(void* x, const void* ln_w, float eps, const void* q
         O3V_KLAUNCH((decode_attn_block_kernel<A, B>), grid, block, shmem, stream, a);                    \
         launched = true;                                                                                 \
     }
-    O3V_FUSED_SHAPES(O3V_X)
+    if (!qkn) {
+        O3V_FUSED_SHAPES(O3V_X)
+    }
+#undef O3V_X
+#define O3V_X(A, B)                                                                                      \
+    if (!launched && nstep == A && wb == B) {                                                            \
+        static const int cap = fused_capacity<A, B, true>(shmem);                                        \
+        if (nb_attn + nb_o >= cap) return O3V_ERR_SHAPE;                                                 \
+        O3V_KLAUNCH((decode_attn_block_kernel<A, B, true>), grid, block, shmem, stream, a);              \
+        launched = true;                                                                                 \
+    }
+    if (qkn) {
+        O3V_FUSED_SHAPES_QKN(O3V_X)
+    }
 #undef O3V_X
     if (!launched) return O3V_ERR_SHAPE;
     O3V_CHECK_LAUNCH();
@@ -305,8 +342,9 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
                                      float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot,
                                      int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
                                      uint32_t epoch, hipStream_t stream) {
-    return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, cosT, sinT, q_buf, att_buf, kcache, vcache, part_o,
-                             part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync, epoch, stream);
+    return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, nullptr, nullptr, nullptr, cosT, sinT, q_buf, att_buf,
+                             kcache, vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync,
+                             epoch, stream);
 }
 
 // the same with fp8 (OCP e4m3fn) rows + per-row scales for the two projections (o3v_linear_decode_fp8's weight format)
@@ -316,6 +354,23 @@ extern "C" int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, c
                                          const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax, int cs_stride_row,
                                          int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch, hipStream_t stream) {
     if (!qkv_s || !o_s) return O3V_ERR_ARG;
-    return attn_block_launch(x, ln_w, eps, qkv_w8, qkv_s, qkv_b, o_w8, o_s, cosT, sinT, q_buf, att_buf, kcache, vcache, part_o,
-                             part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync, epoch, stream);
+    return attn_block_launch(x, ln_w, eps, qkv_w8, qkv_s, qkv_b, o_w8, o_s, nullptr, nullptr, nullptr, cosT, sinT, q_buf, att_buf,
+                             kcache, vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync,
+                             epoch, stream);
+}
+
+// Qwen3-VL form (TF3:438-500): no q/k/v bias, RMSNorm weights q_norm / k_norm [D] on every q and k head between the projection
+// and the rotation.  kv_raw: (Hq + 2 * Hkv) * D bf16 of scratch (the un-normalised k, v and q of this token); qkv_s / o_s non-NULL select
+// fp8 rows as in o3v_decode_attn_block_fp8.  Bit-identical to o3v_linear_decode(q/k/v) + o3v_qkv_norm_rope_cache +
+// o3v_attn_decode + o3v_linear_decode(o_proj, RESIDUAL).
+extern "C" int o3v_decode_attn_block_qknorm(void* x, const void* ln_w, float eps, const void* qkv_w, const float* qkv_s,
+                                            const void* o_w, const float* o_s, const void* q_norm, const void* k_norm, void* kv_raw,
+                                            const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
+                                            float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot,
+                                            int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
+                                            uint32_t epoch, hipStream_t stream) {
+    if (!q_norm || !k_norm || !kv_raw) return O3V_ERR_ARG;
+    return attn_block_launch(x, ln_w, eps, qkv_w, qkv_s, nullptr, o_w, o_s, q_norm, k_norm, kv_raw, cosT, sinT, q_buf, att_buf, kcache,
+                             vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync, epoch,
+                             stream);
 }

@@ -730,7 +730,7 @@ template <int M, bool NORM, int WB = 2>
 int launch_gemv_m(const GemvArgs& a) {
 #ifdef O3V_TUNE
     if (g_tune_R) {
-#define O3V_T(RR, KK) if (g_tune_R == RR && g_tune_KS == KK) return launch_gemv<M, RR, KK, NORM>(a)
+#define O3V_T(RR, KK) if (g_tune_R == RR && g_tune_KS == KK) return launch_gemv<M, RR, KK, NORM, 4, WB>(a)
         O3V_T(2, 1); O3V_T(2, 2); O3V_T(2, 4); O3V_T(4, 1); O3V_T(4, 2); O3V_T(4, 4); O3V_T(8, 1); O3V_T(8, 2);
 #undef O3V_T
         return O3V_ERR_ARG;

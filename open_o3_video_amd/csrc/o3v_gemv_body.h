@@ -60,6 +60,7 @@ struct RopeArgs {  // EPI_QKVROPE destinations (one token per row m, cache slot 
     const bf16_t *cosT, *sinT;
     bf16_t *qout, *kc, *vc;
     int slot, Hq, Hkv, D, Tmax, cs_stride, cs_off;
+    int raw = 0;  // 1: no rotation (cos = 1, sin = 0; cosT / sinT unused) -- the q/k norm of Qwen3-VL comes first, elsewhere
 };
 
 // PUB: the outputs (q and the new K/V row; a SwiGLU / plain output row) are handed to other workgroups of the SAME launch
@@ -146,8 +147,8 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + jj;
-            e_cos[m] = bf2f(ra.cosT[cs]);
-            e_sin[m] = bf2f(ra.sinT[cs]);
+            e_cos[m] = ra.raw ? 1.0f : bf2f(ra.cosT[cs]);  // raw: x * 1 + (-y) * 0 == x exactly
+            e_sin[m] = ra.raw ? 0.0f : bf2f(ra.sinT[cs]);
         }
     }
     // K-slice in whole 64-chunk steps

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -376,6 +377,8 @@ class O3VEngine:
         # so that the grid stays near 640 blocks (measured, 7B: 8 rows 40 -> 20 splits 3.85 -> 3.72 ms/step; 16 independent rows
         # 32 -> 8 splits 2020 -> 2128 tok/s; 2 and 4 rows are best at 40)
         nsplit = max(1, min(64, (S + T + 127) // 128, max(1, 640 // max(1, B * tc.num_key_value_heads))))
+        if os.environ.get("O3V_NSPLIT"):      # A/B switch (tools/probes)
+            nsplit = int(os.environ["O3V_NSPLIT"])
         # G completions of a prompt share its K/V: the group kernel reads the prompt keys once per group (head_dim 128,
         # G * n_rep <= 64 query rows per kv head, prefix splits + own-key splits <= 64)
         n_rep = tc.num_attention_heads // tc.num_key_value_heads

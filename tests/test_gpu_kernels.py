@@ -883,6 +883,87 @@ def test_decode_attn_block_fused_equals_three_launches(dev, Hq, Hkv, H, ctx, Tma
 
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("Hq,Hkv,H,ctx,Tmax,nsplit,pad", [
+    (32, 8, 4096, 3563, 3820, 20, 0),      # Qwen3-VL-8B text dims, one 32-frame prompt
+    (32, 8, 4096, 300, 512, 4, 5),         # short context: the newest key's split is not the last one
+    (8, 2, 1024, 61, 80, 1, 0),            # fixture dims (tests/fixture_models_q3.py medium), one split
+    (8, 2, 1024, 700, 1024, 9, 0),
+    (32, 8, 4096, 1, 64, 1, 0),            # one key (the token itself)
+])
+def test_decode_attn_block_qknorm_equals_stand_alone_chain(dev, Hq, Hkv, H, ctx, Tmax, nsplit, pad, fp8):
+    """o3v_decode_attn_block_qknorm (Qwen3-VL: q/k RMSNorm between projection and rotation, done inside the attention role) ==
+    o3v_linear_decode[_fp8](q/k/v) + o3v_qkv_norm_rope_cache + o3v_attn_decode + o3v_linear_decode[_fp8](o_proj, RESIDUAL) BIT FOR
+    BIT: residual stream, attention output, the appended K/V row.  Three epochs on one sync buffer."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import quantize_rows_fp8
+    D, Tnew, step = 128, 7, 3
+    slot = ctx - 1
+    g = torch.Generator().manual_seed(Hq * 1000 + ctx)
+    N, QD = (Hq + 2 * Hkv) * D, Hq * D
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    qn = (1 + 0.2 * torch.randn(D, generator=g)).to(BF).to(dev)
+    kn = (1 + 0.2 * torch.randn(D, generator=g)).to(BF).to(dev)
+    wqkv = (torch.randn(N, H, generator=g) / math.sqrt(H)).to(BF).to(dev)
+    wo = (torch.randn(H, QD, generator=g) / math.sqrt(QD)).to(BF).to(dev)
+    w8 = s8 = o8 = so8 = None
+    if fp8:
+        w8, s8 = quantize_rows_fp8(wqkv)
+        o8, so8 = quantize_rows_fp8(wo)
+    ang = torch.rand(1, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    kc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    vc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    kc0[:, :, slot] = float("nan")
+    vc0[:, :, slot] = float("nan")
+    k_lo = torch.tensor([pad], dtype=torch.int32, device=dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
+    part_o = torch.empty(Hq * 64 * D, dtype=torch.float32, device=dev)
+    part_ml = torch.empty(Hq * 64 * 2, dtype=torch.float32, device=dev)
+    q2, att2 = torch.zeros(1, Hq, D, dtype=BF, device=dev), torch.zeros(1, Hq, D, dtype=BF, device=dev)
+    raw2 = torch.zeros((Hq + 2 * Hkv) * D, dtype=BF, device=dev)
+    k2, v2 = kc0.clone(), vc0.clone()
+    for rep in range(3):
+        x0 = (torch.randn(1, H, generator=g) * 2).to(BF).to(dev)
+        x1 = x0.clone()
+        qkv1 = torch.zeros(1, N, dtype=BF, device=dev)
+        q1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        k1, v1 = kc0.clone(), vc0.clone()
+        att1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        po1, pm1 = torch.empty_like(part_o), torch.empty_like(part_ml)
+        if fp8:
+            _lib.call("o3v_linear_decode_fp8", P(x1), P(nw), 1e-6, P(w8), P(s8), None, None, P(qkv1), 1, N, H, H, N, 0, _lib.EPI_NONE, st)
+        else:
+            _lib.call("o3v_linear_decode", P(x1), P(nw), 1e-6, P(wqkv), None, None, None, P(qkv1), 1, N, H, H, N, 0, _lib.EPI_NONE, st)
+        _lib.call("o3v_qkv_norm_rope_cache", P(qkv1), P(qn), P(kn), 1e-6, P(cos), P(sin), P(q1), P(k1), P(v1), slot, 1, 1, Hq, Hkv, D, Tmax,
+                  Tnew, step, st)
+        _lib.call("o3v_attn_decode", P(q1), P(k1), P(v1), P(att1), P(po1), P(pm1), P(k_lo), 1, Hq, Hkv, D, ctx, Tmax, nsplit, scale, st)
+        if fp8:
+            _lib.call("o3v_linear_decode_fp8", P(att1), None, 0.0, P(o8), P(so8), None, P(x1), P(x1), 1, H, QD, QD, H, H, _lib.EPI_RESIDUAL, st)
+        else:
+            _lib.call("o3v_linear_decode", P(att1), None, 0.0, P(wo), None, None, P(x1), P(x1), 1, H, QD, QD, H, H, _lib.EPI_RESIDUAL, st)
+        x2 = x0.clone()
+        k2[:, :, slot] = float("nan")
+        v2[:, :, slot] = float("nan")
+        rc = lib.o3v_decode_attn_block_qknorm(P(x2), P(nw), 1e-6, P(w8 if fp8 else wqkv), P(s8), P(o8 if fp8 else wo), P(so8), P(qn), P(kn),
+                                              P(raw2), P(cos), P(sin), P(q2), P(att2), P(k2), P(v2), P(part_o), P(part_ml), P(k_lo), H, Hq,
+                                              Hkv, D, slot, Tmax, Tnew, step, nsplit, scale, P(sync), rep + 1, st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        tmo = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+        assert tmo == 0, f"an in-launch wait timed out (code {tmo:#x})"
+        assert not torch.isnan(x1.float()).any()
+        assert torch.equal(k2.view(torch.int16), k1.view(torch.int16)) and torch.equal(v2.view(torch.int16), v1.view(torch.int16))
+        assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
+
+
 @pytest.mark.parametrize("V,top_k,top_p,temp,rep", [(152064, 50, 0.95, 1.0, 1.0), (152064, 1, 1.0, 1.0, 1.0), (152064, 7, 0.9, 0.8, 1.1),
                                                      (152064, 200000, 0.95, 1.0, 1.0), (997, 20, 0.5, 1.0, 1.0), (997, 3, 1.0, 1.3, 1.0)])
 def test_sample_top_k_top_p(dev, V, top_k, top_p, temp, rep):

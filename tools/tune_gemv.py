@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "open_o3_video_amd", "csrc")
-OUT = os.path.join(ROOT, "gpurun_out", "libo3v_tune.so")
+OUT = os.path.join(ROOT, "open_o3_video_amd", "build", "libo3v_tune.so")
 
 
 def build():
@@ -27,6 +27,8 @@ def main():
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     lib.o3v_gemv_norm_bf16.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.o3v_gemv_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.o3v_linear_decode_fp8.argtypes = [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    fp8 = "--fp8" in sys.argv     # fp8 (e4m3fn) weight rows + per-row scales: the same decompositions on rows half as long
     dev = torch.device("cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     H, I = 3584, 18944
@@ -34,12 +36,16 @@ def main():
         "gate_up": (2 * I, H, 3, True), "down": (H, I, 1, False), "o_proj": (H, H, 1, False), "qkv": (4608, H, 0, True),
         "lm_head": (152064, H, 0, True),
     }
-    variants = [(2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)]
+    variants = [(0, 0), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)]   # (0, 0): the library's own choice
     L = 28
     g = torch.Generator(device=dev).manual_seed(0)
     for name, (N, K, epi, norm) in shapes.items():
         nl = 4 if name == "lm_head" else L
-        ws = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).normal_(0, 0.02, generator=g) for _ in range(nl)]
+        if fp8:
+            ws = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev, generator=g) for _ in range(nl)]
+            sc = torch.full((N,), 2.0 ** -8, dtype=torch.float32, device=dev)
+        else:
+            ws = [torch.empty(N, K, dtype=torch.bfloat16, device=dev).normal_(0, 0.02, generator=g) for _ in range(nl)]
         x = torch.randn(1, K, device=dev).to(torch.bfloat16)
         nw = torch.ones(K, dtype=torch.bfloat16, device=dev)
         res = torch.zeros(1, N, dtype=torch.bfloat16, device=dev)
@@ -50,7 +56,10 @@ def main():
         def run(v):
             lib.o3v_gemv_tune(*v)
             for w in ws:
-                if norm:
+                if fp8:
+                    rc = lib.o3v_linear_decode_fp8(P(x), P(nw) if norm else None, 1e-6, P(w), P(sc), None, P(res), P(out), 1, N, K, K, No, N,
+                                                   epi, st)
+                elif norm:
                     rc = lib.o3v_gemv_norm_bf16(P(x), P(nw), 1e-6, P(w), None, P(res), P(out), 1, N, K, K, K, No, N, epi, st)
                 else:
                     rc = lib.o3v_gemv_bf16(P(x), P(w), None, P(res), P(out), 1, N, K, K, K, No, N, epi, st)
@@ -71,7 +80,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 results[v].append(e0.elapsed_time(e1) * 1e3 / nl)
-        mb = N * K * 2 / 1e6
+        mb = N * K * (1 if fp8 else 2) / 1e6
         line = f"{name:8s} {mb:7.1f} MB  " + "  ".join(f"R{v[0]}K{v[1]}:{sorted(t)[len(t) // 2]:6.1f}us" for v, t in results.items())
         best = min(results, key=lambda v: sorted(results[v])[len(results[v]) // 2])
         bt = sorted(results[best])[len(results[best]) // 2]
