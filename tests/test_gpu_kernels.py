@@ -53,6 +53,98 @@ def test_rmsnorm(dev):
         close_bf16(out, ref, ulps=1, atol=0, frac=1.0)
 
 
+def test_layernorm(dev):
+    """o3v_layernorm (Qwen3-VL vision blocks and mergers) vs F.layer_norm on the bf16 inputs (fp32 statistics, one rounding), with a
+    padded output stride."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rows, cols, ldo in [(1, 64, 64), (5, 288, 320), (37, 1152, 1152), (130, 4608, 4608), (3, 72, 128)]:
+        x = (torch.randn(rows, cols, generator=g) * 3 + 0.5).to(BF)
+        w = (1 + 0.1 * torch.randn(cols, generator=g)).to(BF)
+        b = (0.2 * torch.randn(cols, generator=g)).to(BF)
+        out = torch.full((rows, ldo), 7.0, dtype=BF, device=dev)
+        xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+        _lib.call("o3v_layernorm", P(xd), P(wd), P(bd), P(out), rows, cols, cols, ldo, 1e-6, st)
+        ref = torch.nn.functional.layer_norm(x.float(), (cols,), w.float(), b.float(), 1e-6)
+        close_bf16(out[:, :cols], ref, ulps=1, atol=1e-3, frac=0.999)
+        assert (out[:, cols:] == 7.0).all()
+
+
+def test_gemm_gelu_tanh_epilogue(dev):
+    """EPI_GELU_TANH of the MFMA GEMM (Qwen3-VL vision fc1) vs F.gelu(approximate="tanh") of the bf16-rounded linear output."""
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    for M, N, K in [(72, 96, 64), (160, 4352, 1152), (520, 448, 320), (4, 128, 64)]:
+        a = torch.randn(M, K, generator=g).to(BF).to(dev)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+        bias = (0.3 * torch.randn(N, generator=g)).to(BF).to(dev)
+        for tile in (128, 256):
+            out = ops.gemm(a, w, bias, None, _lib.EPI_GELU_TANH, force="gemm", tile=tile)
+            lin = rb(a.float() @ w.float().t() + bias.float())
+            close_bf16(out, torch.nn.functional.gelu(lin, approximate="tanh"), ulps=1, atol=1e-3, frac=0.999)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,T,tpr", [(128, 8, 2, 37, 37), (128, 32, 8, 3, 1), (32, 4, 2, 21, 7), (64, 4, 4, 5, 5)])
+def test_qkv_norm_rope_cache(dev, D, Hq, Hkv, T, tpr):
+    """o3v_qkv_norm_rope_cache (Qwen3-VL: RMSNorm on every q / k head, then the rotation, then the cache append) vs the oracle's
+    rmsnorm + rotate_half arithmetic in bf16 (TF3:480-484).  The sum of squares is taken in another order than torch's: 1 bf16 ulp
+    on a small fraction of entries; v rows and untouched slots exactly."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(D + T)
+    B, Tmax, slot0 = T // tpr, tpr + 9, 4
+    HT = Hq + 2 * Hkv
+    qkv = (torch.randn(T, HT * D, generator=g) * 1.5).to(BF)
+    qn = (1 + 0.2 * torch.randn(D, generator=g)).to(BF)
+    kn = (1 + 0.2 * torch.randn(D, generator=g)).to(BF)
+    ang = torch.rand(T, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF)
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    qo = torch.zeros(T, Hq, D, dtype=BF, device=dev)
+    kc = torch.zeros(B, Hkv, Tmax, D, dtype=BF, device=dev)
+    vc = torch.zeros_like(kc)
+    qkvd, qnd, knd, cosd, sind = qkv.to(dev), qn.to(dev), kn.to(dev), cos.to(dev), sin.to(dev)
+    _lib.call("o3v_qkv_norm_rope_cache", P(qkvd), P(qnd), P(knd), 1e-6, P(cosd), P(sind), P(qo), P(kc), P(vc), slot0, T, tpr, Hq, Hkv, D,
+              Tmax, tpr, 0, st)
+    q, k, v = qkv.view(T, HT, D).split([Hq, Hkv, Hkv], dim=1)
+    c4, s4 = cos.view(T, 1, D), sin.view(T, 1, D)
+    qr = model_ref.rmsnorm(q, qn, 1e-6)
+    kr = model_ref.rmsnorm(k, kn, 1e-6)
+    q_ref = (qr * c4) + (model_ref.rotate_half(qr) * s4)
+    k_ref = (kr * c4) + (model_ref.rotate_half(kr) * s4)
+    close_bf16(qo, q_ref, ulps=1, atol=1e-3, frac=0.995)
+    kgot = kc.cpu()[:, :, slot0:slot0 + tpr].transpose(1, 2).reshape(T, Hkv, D)
+    close_bf16(kgot, k_ref, ulps=1, atol=1e-3, frac=0.995)
+    assert torch.equal(vc.cpu()[:, :, slot0:slot0 + tpr].transpose(1, 2).reshape(T, Hkv, D), v)
+    assert (kc[:, :, :slot0] == 0).all() and (kc[:, :, slot0 + tpr:] == 0).all()
+
+
+def test_add_rows(dev):
+    """o3v_add_rows (DeepStack, TF3:839-862): x[rows[i]] = bf16(x[rows[i]] + feat[src[i]]), other rows untouched."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    H, T, n = 1024, 50, 17
+    x = torch.randn(T, H, generator=g).to(BF)
+    feat = torch.randn(30, H, generator=g).to(BF)
+    rows = torch.randperm(T, generator=g)[:n].to(torch.int32)
+    src = torch.randint(0, 30, (n,), generator=g).to(torch.int32)
+    xd = x.to(dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    rd, sd, fd = rows.to(dev), src.to(dev), feat.to(dev)
+    _lib.call("o3v_add_rows", P(xd), P(rd), P(sd), P(fd), n, H, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ref = x.clone()
+    ref[rows.long()] = (x[rows.long()].float() + feat[src.long()].float()).to(BF)
+    assert torch.equal(xd.cpu(), ref)
+
+
 def _epi_ref(acc, bias, res, epi):
     import kernel_ops as ops
     v = acc + (bias.float() if bias is not None else 0)

@@ -170,3 +170,85 @@ def test_generation_config_resolution_matches_hf(golden_dir, tmp_path):
     # the unset trainer fields fall back to HF's global defaults when the checkpoint says nothing
     r = resolve_generation_config(passed, GenerationConfigLike(), {})
     assert r["top_k"] == 50 and r["repetition_penalty"] == 1.0 and r["eos_token_id"] is None
+
+
+# ------------------------------------------------------------------------------------------------ Qwen3-VL host logic
+def test_qwen3vl_config_parsing():
+    from open_o3_video_amd.config import qwen3vl_8b_dict
+    import fixture_models_q3 as fq
+    c = O3VConfig.from_dict(qwen3vl_8b_dict())
+    assert c.arch == "qwen3_vl" and c.vision.patch_size == 16 and c.vision.head_dim == 72 and c.vision.head_dim_pad == 80
+    assert c.vision.hidden_pad == 1152 and c.vision.inter_pad == 4352 and c.vision.deepstack_visual_indexes == [8, 16, 24]
+    assert c.text.head_dim == 128 and c.text.qk_norm and c.text.mrope_interleaved and not c.text.attention_bias
+    assert c.text.mrope_section == [24, 20, 20] and c.text.rope_theta == 5000000.0
+    m = O3VConfig.from_dict(fq.medium_q3_config())
+    assert m.vision.hidden_pad == 320 and m.vision.head_dim_pad == 80 and m.text.head_dim == 128
+    # the HF 5.x layout keeps the rope settings under rope_parameters
+    d = fq.medium_q3_config()
+    tc = d["text_config"]
+    tc["rope_parameters"] = {"rope_type": "default", "mrope_section": tc.pop("mrope_section"), "rope_theta": tc.pop("rope_theta"),
+                             "mrope_interleaved": True}
+    m2 = O3VConfig.from_dict(d)
+    assert m2.text.mrope_section == [24, 20, 20] and m2.text.rope_theta == 5000000.0 and m2.text.mrope_interleaved
+    q25 = O3VConfig.from_dict(qwen25vl_7b_dict())
+    assert q25.arch == "qwen2_5_vl" and not q25.text.qk_norm and q25.text.attention_bias and not q25.text.mrope_interleaved
+    bad = qwen3vl_8b_dict()
+    bad["text_config"]["attention_bias"] = True
+    with pytest.raises(ValueError):
+        O3VConfig.from_dict(bad)
+
+
+def test_qwen3vl_pos_embed_taps_and_interleaved_mrope_match_oracle():
+    """indexing.pos_embed_taps / mrope_axis_table_interleaved (product, numpy) == oracle/model_ref_q3 (torch), which is pinned to
+    transformers' Qwen3-VL by goldens G12 / G13: table rows and fp32 weights bit for bit, rotary angles bit for bit."""
+    from oracle import model_ref_q3 as q3
+    for grid, side in [(((1, 4, 6), (2, 8, 4)), 8), (((3, 14, 26),), 48), (((1, 2, 2),), 12), (((2, 16, 10), (1, 6, 6)), 16)]:
+        i1, w1 = indexing.pos_embed_taps(grid, side, 2)
+        i2, w2 = q3.pos_embed_taps(list(grid), side, 2)
+        assert np.array_equal(i1, i2.numpy()) and np.array_equal(w1, w2.numpy()), grid
+        assert np.allclose(w1.sum(1), 1.0, atol=1e-6) and i1.min() >= 0 and i1.max() < side * side
+    for sec, half in (([24, 20, 20], 64), ([6, 5, 5], 16)):
+        cfg = {"text_config": {"head_dim": 2 * half, "rope_theta": 5e6, "mrope_section": sec}}
+        ax = indexing.mrope_axis_table_interleaved(sec, half)
+        pos = torch.from_numpy(np.random.RandomState(1).randint(0, 4000, (3, 2, 9)))
+        c, s = q3.interleaved_mrope_cos_sin(cfg, pos, torch.float32)
+        inv = 1.0 / (5e6 ** (torch.arange(0, 2 * half, 2, dtype=torch.float) / (2 * half)))
+        for b in range(2):
+            f = pos.float()[torch.from_numpy(ax).long(), b, :].T * inv
+            assert torch.equal(torch.cat([f, f], -1).cos(), c[b]) and torch.equal(torch.cat([f, f], -1).sin(), s[b])
+        assert (ax == 0).sum() == sec[0] and (ax == 1).sum() == sec[1] and (ax == 2).sum() == sec[2]
+
+
+def test_deepstack_rows():
+    ids = np.asarray([[5, 9, 9, 9, 7, 9, 9, 3]])
+    rows, src = indexing.deepstack_rows(ids, 9)
+    assert rows.tolist() == [1, 2, 3, 5, 6] and src.tolist() == [0, 1, 2, 3, 4]
+    rows, src = indexing.deepstack_rows(ids, 9, first=3)          # a cached prefix of 3 tokens: later visual rows keep their ordinal
+    assert rows.tolist() == [0, 2, 3] and src.tolist() == [2, 3, 4]
+    rows, src = indexing.deepstack_rows(np.asarray([[1, 2], [9, 4]]), 9)   # flattened batch rows
+    assert rows.tolist() == [2] and src.tolist() == [0]
+
+
+def test_qwen3vl_vision_head_padding_layout():
+    """weights._pack_vision_q3's head layout, restated: heads of 72 stored 80 wide as [36 | 4 zeros | 36 | 4 zeros] keep q.k and
+    the rotation pairs (j, j + 36) intact when the kernels pair (j, j + 40)."""
+    hd, Dp, heads = 72, 80, 3
+    half, halfp = hd // 2, Dp // 2
+    j = np.arange(Dp)
+    inner = np.where(j < halfp, j, j - halfp)
+    src = np.where(j < halfp, inner, inner + half)
+    valid = inner < half
+    rng = np.random.default_rng(0)
+    q, k = rng.standard_normal((heads, hd)), rng.standard_normal((heads, hd))
+    qp = np.where(valid, q[:, np.minimum(src, hd - 1)], 0.0)
+    kp = np.where(valid, k[:, np.minimum(src, hd - 1)], 0.0)
+    assert np.allclose((qp * kp).sum(1), (q * k).sum(1))
+    ang = rng.standard_normal(half)
+    cos, sin = np.ones(halfp), np.zeros(halfp)
+    cos[:half], sin[:half] = np.cos(ang), np.sin(ang)
+
+    def rot(x, c, s, h):       # rotate_half with pairs (j, j + h)
+        return np.concatenate([x[:, :h] * c - x[:, h:] * s, x[:, h:] * c + x[:, :h] * s], axis=1)
+    want = rot(q, np.cos(ang), np.sin(ang), half)
+    got = rot(qp, cos, sin, halfp)
+    assert np.allclose(got[:, valid], want[:, src[valid]]) and np.allclose(got[:, ~valid], 0.0)

@@ -205,3 +205,11 @@ if "q3" in which:
                               "weights_GB": round(eng.w.nbytes() / 1e9, 2)}), flush=True)
         del eng
         torch.cuda.empty_cache()
+
+if "rollout_long" in which:
+    # G = 16 completions behind a 20k-token prompt (256 frames 224x224) -- the prompt's K/V is kept once
+    # (kv_cache_GB counts the shared entry + the 16 rows' own tokens; one prompt's K/V at S = 20394 is 1.17 GB)
+    cfg = O3VConfig.from_dict(qwen25vl_7b_dict())
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev))
+    run("rollout G=16 sampled top_p=0.95 (LONG 256x224x224, S=20394)", 256, 224, 224, 256 * (64 + 15) + 170, 128, num_return_sequences=16,
+        do_sample=True, top_p=0.95, temperature=1.0, seed=1)
