@@ -161,7 +161,7 @@ def kernel_roofline(eng, reps=3):
             traffic = pm["hbm_bytes_per_launch"]
     except OSError:
         pass
-    return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=4,KS=1,SWIGLU,NORM> (RMSNorm + LLM gate/up projection, decode)",
+    return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=2,KS=1,SWIGLU,NORM> (RMSNorm + LLM gate/up projection, decode)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": "profiles/r01_gemv_pmc.json (rocprofv3 --pmc passes of this kernel on this shape; "
                                                   "not a counter of this run)" if traffic is not None else None,

@@ -743,9 +743,13 @@ int launch_gemv_m(const GemvArgs& a) {
     if (a.epi == EPI_QKVROPE) return launch_gemv_balanced<M, 1, NORM, WB>(a);
     if (a.epi == EPI_SWIGLU) {
         // (fp8 rows, half as long: 4 pairs per wave measured slower, 1.958 vs 1.864 ms per decode step at 7B dims)
+        // one row of bf16 weights: one (gate, up) pair per wave -- re-measured in round 2 (profiles/r02_gemv_tune_bf16.txt:
+        // 42.4 vs 43.5 us at 7B dims, decode step 2.72 -> 2.685 ms); two pairs per wave stay for fp8 rows and for two rows of x
+        if (M == 1 && WB == 2 && outs >= 8192) return launch_gemv<M, 2, 1, NORM, 4, WB>(a);
         if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);  // 2 (gate,up) pairs per wave
         return launch_gemv<M, 2, 1, NORM, 4, WB>(a);
     }
+    if (M == 1 && WB == 2 && outs >= 32768) return launch_gemv<M, 2, 1, NORM, 4, WB>(a);  // lm_head, one bf16 row: 154.0 vs 156.4 us
     if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);     // lm_head
     if (steps >= 16) return launch_gemv_balanced<M, 2, NORM, WB>(a);           // long K (down_proj): split K over wave pairs
     return launch_gemv_balanced<M, 1, NORM, WB>(a);                            // o_proj / qkv
