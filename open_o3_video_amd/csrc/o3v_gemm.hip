@@ -369,15 +369,15 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------
 // Small-M weight-streaming GEMV (decode): body in o3v_gemv_body.h (shared with the fused decode launch).
 // ------------------------------------------------------------------------------------------------
-template <int M, int R, int KS, int EPI, bool NORM, int NW = 4, int WB = 2>
+template <int M, int R, int KS, int EPI, bool NORM, int NW = 4, int WB = 2, int UU = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                             bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
                                                             float eps, int N, int K, int ldx, int ldw, int ldo, int ldr,
                                                             RopeArgs ra, const float* __restrict__ wscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M*K bf16] [KS>1: NW*R*M f32] [NORM: NW*M f32]
-    gemv_body<M, R, KS, EPI, NORM, false, 0, NW, WB>(X, W, bias, res, out, norm_w, eps, N, K, ldx, ldw, ldo, ldr, ra, blockIdx.x, smem,
-                                                     wscale);
+    gemv_body<M, R, KS, EPI, NORM, false, UU, NW, WB>(X, W, bias, res, out, norm_w, eps, N, K, ldx, ldw, ldo, ldr, ra, blockIdx.x, smem,
+                                                      wscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -661,7 +661,7 @@ struct GemvArgs {
     const float* wscale = nullptr;  // fp8 weights (M <= 3): one dequantisation scale per output row; W then points at bytes
 };
 
-template <int M, int R, int KS, bool NORM, int NW = 4, int WB = 2>
+template <int M, int R, int KS, bool NORM, int NW = 4, int WB = 2, int UU = 0>
 int launch_gemv(const GemvArgs& a) {
     const int per_wave = (a.epi == EPI_SWIGLU) ? R / 2 : (a.epi == EPI_QKVROPE ? 1 : R);
     const int outs = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 2 : a.N;
@@ -670,7 +670,7 @@ int launch_gemv(const GemvArgs& a) {
     const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)NW * R * M * 4 + (NORM ? NW * M * 4 : 0);
     if (shmem > 160 * 1024) return O3V_ERR_SHAPE;
 #define O3V_GV(E)                                                                                                             \
-    O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM, NW, WB>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, \
+    O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM, NW, WB, UU>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, \
                 a.eps, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, a.wscale)
     switch (a.epi) {
         case EPI_QKVROPE:
@@ -733,6 +733,14 @@ int launch_gemv_m(const GemvArgs& a) {
 #define O3V_T(RR, KK) if (g_tune_R == RR && g_tune_KS == KK) return launch_gemv<M, RR, KK, NORM, 4, WB>(a)
         O3V_T(2, 1); O3V_T(2, 2); O3V_T(2, 4); O3V_T(4, 1); O3V_T(4, 2); O3V_T(4, 4); O3V_T(8, 1); O3V_T(8, 2);
 #undef O3V_T
+        // R = 2, KS = 1 with other workgroup sizes (g_tune_R = 100 + NW) and trip depths (g_tune_KS = k-steps per trip)
+#define O3V_T2(NN, UV) if (g_tune_R == 100 + NN && g_tune_KS == UV) return launch_gemv<M, 2, 1, NORM, NN, WB, UV>(a)
+        O3V_T2(4, 2); O3V_T2(4, 4); O3V_T2(4, 8); O3V_T2(8, 4); O3V_T2(8, 2); O3V_T2(16, 4); O3V_T2(2, 4); O3V_T2(8, 8);
+        O3V_T2(1, 4); O3V_T2(1, 2); O3V_T2(2, 2); O3V_T2(3, 4); O3V_T2(2, 6); O3V_T2(1, 6);
+#define O3V_T4(NN, UV) if (g_tune_R == 200 + NN && g_tune_KS == UV) return launch_gemv<M, 4, 1, NORM, NN, WB, UV>(a)
+        O3V_T4(2, 2); O3V_T4(3, 2); O3V_T4(2, 4); O3V_T4(4, 4); O3V_T4(8, 2); O3V_T4(2, 1);
+#undef O3V_T4
+#undef O3V_T2
         return O3V_ERR_ARG;
     }
 #endif
@@ -745,11 +753,13 @@ int launch_gemv_m(const GemvArgs& a) {
         // (fp8 rows, half as long: 4 pairs per wave measured slower, 1.958 vs 1.864 ms per decode step at 7B dims)
         // one row of bf16 weights: one (gate, up) pair per wave -- re-measured in round 2 (profiles/r02_gemv_tune_bf16.txt:
         // 42.4 vs 43.5 us at 7B dims, decode step 2.72 -> 2.685 ms); two pairs per wave stay for fp8 rows and for two rows of x
-        if (M == 1 && WB == 2 && outs >= 8192) return launch_gemv<M, 2, 1, NORM, 4, WB>(a);
+        // (and two waves per workgroup: 41.7 us; 4 waves 42.5, 3 waves 42.1, 1 wave 45.4 -- profiles/r02_gemv_tune_wg.txt)
+        if (M == 1 && WB == 2 && outs >= 8192) return launch_gemv<M, 2, 1, NORM, 2, WB>(a);
         if (M <= 2 && outs >= 8192) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);  // 2 (gate,up) pairs per wave
         return launch_gemv<M, 2, 1, NORM, 4, WB>(a);
     }
-    if (M == 1 && WB == 2 && outs >= 32768) return launch_gemv<M, 2, 1, NORM, 4, WB>(a);  // lm_head, one bf16 row: 154.0 vs 156.4 us
+    if (M == 1 && WB == 2 && outs >= 32768) return launch_gemv<M, 2, 1, NORM, 3, WB>(a);  // lm_head, one bf16 row: 152.1 us (R = 4: 156)
+    if (M == 1 && WB == 1 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 3, WB>(a);  // lm_head, one row of fp8 weights: 80.2 vs 82.0 us
     if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);     // lm_head
     if (steps >= 16) return launch_gemv_balanced<M, 2, NORM, WB>(a);           // long K (down_proj): split K over wave pairs
     return launch_gemv_balanced<M, 1, NORM, WB>(a);                            // o_proj / qkv

@@ -40,6 +40,12 @@ def main():
         shapes = {"gate_up": (2 * I, H, 3, True), "gu_2048blk": (2 * 16384, H, 3, True), "gu_2560blk": (2 * 20480, H, 3, True),
                   "gu_4096blk": (2 * 32768, H, 3, True), "down": (H, I, 1, False), "down_4096": (4096, I, 1, False)}
     variants = [(0, 0), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)]   # (0, 0): the library's own choice
+    if "--wg" in sys.argv:        # R = 2, KS = 1 with other workgroup sizes and trip depths: variant (100 + NW, k-steps per trip)
+        variants = [(0, 0), (104, 4), (102, 4), (102, 2), (102, 6), (101, 4), (101, 2), (101, 6), (103, 4)]
+        shapes = {k: shapes[k] for k in ("gate_up", "down", "lm_head")}
+    if "--wg4" in sys.argv:       # R = 4 (two pairs per wave; the fp8 choice) with other workgroup sizes / trip depths
+        variants = [(0, 0), (4, 1), (202, 2), (203, 2), (202, 4), (204, 4), (208, 2), (202, 1), (102, 4), (103, 4)]
+        shapes = {k: shapes[k] for k in ("gate_up", "down", "lm_head")}
     L = 28
     g = torch.Generator(device=dev).manual_seed(0)
     for name, (N, K, epi, norm) in shapes.items():
