@@ -290,3 +290,49 @@ def test_3b_dims_tied_head(need_big_gpu):
     finally:
         eng.fused_decode = True
     assert torch.equal(a.sequences, b.sequences) and torch.equal(a.margins, b.margins)
+
+
+def test_qwen3vl_8b_dims(need_big_gpu):
+    """BASELINE config #5's model at its true dimensions (Qwen3-VL-8B: 27 vision blocks of 1152 with heads of 72, three DeepStack
+    taps, 36 decoder layers of 4096 / 12288 with 32 query / 8 kv heads of 128, q/k norm, interleaved M-RoPE), random weights,
+    8 frames 224x416: the decode kernels (one-launch attention block with the q/k norm) and the prefill kernels agree at safe
+    margins, the one-launch form equals the stand-alone kernels bit for bit, frames are independent images in the tower, and
+    the fp8 decode rows follow the bf16 rows wherever the margin is safe."""
+    from open_o3_video_amd.config import O3VConfig, qwen3vl_8b_dict
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, random_getter
+    cfg = O3VConfig.from_dict(qwen3vl_8b_dict())
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 21, "cuda", std=0.02, head_std=0.08), "cuda", batched_decode=False,
+                                       fp8_decode=True))
+    F, H, W = 8, 224, 416
+    tpf = (H // 32) * (W // 32)
+    ids = _prompt(cfg, F, tpf, seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    eng.w.llm.layer[0].qkv_w8, keep = 0, eng.w.llm.layer[0].qkv_w8          # bf16 rows first (the fp8 flag reads layer 0)
+    a, n_safe, floor = _decode_vs_prefill(eng, ids, frames, 24)
+    assert n_safe >= 4
+    try:
+        eng.fused_decode = False
+        b = eng.generate([ids], None, frames=frames, max_new_tokens=24)
+    finally:
+        eng.fused_decode = True
+    assert torch.equal(a.sequences[:, :len(ids)], b.sequences[:, :len(ids)])
+    if torch.equal(a.sequences[0, :len(ids)], torch.tensor(ids, device=a.sequences.device)):
+        assert torch.equal(a.sequences, b.sequences) and torch.equal(a.margins, b.margins)
+    # the tower treats frames as independent images (no attention across temporal patches, per-grid position table)
+    px, grid = eng.pixels_from_frames(frames[:4])
+    v1 = eng.vit_forward(px, grid)
+    perm = torch.tensor([2, 0, 3, 1], device="cuda")
+    px2, grid2 = eng.pixels_from_frames(frames[:4][perm])
+    v2 = eng.vit_forward(px2, grid2)
+    assert torch.equal(v2.view(v2.shape[0], 4, tpf, -1), v1.view(v1.shape[0], 4, tpf, -1)[:, perm])
+    # fp8 rows
+    eng.w.llm.layer[0].qkv_w8 = keep
+    c = eng.generate(a.sequences[:, :len(ids)].cpu().numpy(), None, frames=frames, max_new_tokens=24)
+    ga, gc, m = a.sequences[0, len(ids):].tolist(), c.sequences[0, len(ids):].tolist(), a.margins[0].tolist()
+    k = 0
+    while k < 24 and ga[k] == gc[k]:
+        k += 1
+    print(f"Qwen3-VL-8B dims: fp8 rows follow the bf16 rows for {k}/24 tokens (margin at the split {m[k] if k < 24 else None})")
+    assert k == 24 or m[k] < 16 * floor      # fp8 weights are another model: only a clearly safe margin must survive quantisation
