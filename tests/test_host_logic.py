@@ -65,12 +65,16 @@ def test_tiles():
     t = indexing.segment_tiles(np.asarray([0, 12, 76, 206]))
     assert t.tolist() == [[0, 12, 0, 12, -1, 0, 0, 0], [12, 64, 12, 64, -1, 0, 0, 0], [76, 64, 76, 130, -1, 0, 0, 0],
                           [140, 64, 76, 130, -1, 0, 0, 0], [204, 2, 76, 130, -1, 0, 0, 0]]
+    # causal tiles come longest first (keys a tile walks = causal_off + rows - left padding): same set, heavy ones dispatched first
     p = indexing.prefill_tiles(2, 100, [0, 70], 64)
-    assert p.tolist() == [[0, 64, 0, 100, 0, 0, 0, 0], [64, 36, 0, 100, 64, 0, 0, 0], [164, 36, 0, 100, 64, 70, 1, 0]]
-    assert indexing.prefill_tiles(1, 300, [130]).tolist() == [[128, 128, 0, 300, 128, 130, 0, 0], [256, 44, 0, 300, 256, 130, 0, 0]]
+    assert p.tolist() == [[64, 36, 0, 100, 64, 0, 0, 0], [0, 64, 0, 100, 0, 0, 0, 0], [164, 36, 0, 100, 64, 70, 1, 0]]
+    assert indexing.prefill_tiles(1, 300, [130]).tolist() == [[256, 44, 0, 300, 256, 130, 0, 0], [128, 128, 0, 300, 128, 130, 0, 0]]
     assert indexing.segment_tiles(np.asarray([0])).shape == (0, 8)
     # suffix pass behind a cached prompt prefix of 1000 tokens: queries are rows 0..149, keys slots 0..1149
-    assert indexing.prefill_tiles(1, 150, [0], past=1000).tolist() == [[0, 128, 0, 1150, 1000, 0, 0, 0], [128, 22, 0, 1150, 1128, 0, 0, 0]]
+    assert indexing.prefill_tiles(1, 150, [0], past=1000).tolist() == [[128, 22, 0, 1150, 1128, 0, 0, 0], [0, 128, 0, 1150, 1000, 0, 0, 0]]
+    big = indexing.prefill_tiles(1, 4490, [0])
+    work = big[:, 4] + big[:, 1]
+    assert (np.diff(work) <= 0).all() and sorted(big[:, 0].tolist()) == list(range(0, 4490, 128))
 
 
 def test_embed_source_rows():
