@@ -384,7 +384,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             if (fp8)
                 TRY(o3v_linear_decode_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
                                           O3V_EPI_NONE, s));
-            else
+            else if (norm_apart) {  // (above 16 rows the linears take no fused norm at all)
+                TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+                TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
+            } else
                 TRY(o3v_linear_decode(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
                                       O3V_EPI_NONE, s));
             TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, st->cosT, st->sinT, w.q, kc, vc, slot0 + step, B, 1, Hq,

@@ -110,6 +110,14 @@ def test_q3_group_rollout_and_logps(need_gpu, golden_dir):
     b = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=8, num_return_sequences=2,
                      pad_token_id=cfg["pad_token_id"])
     assert torch.equal(a.sequences[0], b.sequences[0]) and torch.equal(b.sequences[0], b.sequences[1])
+    # 8+ and 17+ rows: q/k/v runs behind a separate norm launch (two MFMA column blocks above 16 rows)
+    for G in (8, 20):
+        c = eng.generate(g["input_ids"], None, pixel_values=pv, image_grid_thw=g["grid"], max_new_tokens=8, num_return_sequences=G,
+                         pad_token_id=cfg["pad_token_id"])
+        k = 0
+        while k < 8 and c.sequences[G - 1, S + k] == a.sequences[0, S + k]:
+            k += 1
+        assert k == 8 or a.margins[0, k].item() < 2 * LOGIT_ATOL, (G, k)
 
 
 def test_q3_prefix_reuse_with_deepstack(need_gpu, golden_dir):
