@@ -180,3 +180,28 @@ def test_q3_through_the_hf_facade(need_gpu, golden_dir):
     assert np.array_equal(out.cpu().numpy(), g["bf16_ids"])
     logits = model(input_ids=torch.from_numpy(g["bf16_ids"]), pixel_values=pv, image_grid_thw=grid).logits
     assert logits.shape == (1, g["bf16_ids"].shape[1], cfg["text_config"]["vocab_size"]) and torch.isfinite(logits.float()).all()
+
+
+def test_q3_through_the_vllm_facade(need_gpu, golden_dir):
+    """vllm_api.LLM over a Qwen3-VL engine: frames under multi_modal_data['image'], one <|image_pad|> per frame, expanded with the
+    model's own resize factor (32) and tokens per frame -- greedy tokens equal HF's (golden G13), from uint8 frames."""
+    from test_gpu_facades import StubTokenizer
+    from open_o3_video_amd.vllm_api import LLM, SamplingParams
+    g, cfg, eng = _load(golden_dir, *CASES[1])
+    llm = LLM(engine=eng, tokenizer=StubTokenizer(cfg), limit_mm_per_prompt={"image": 32}, max_model_len=4096)
+    assert llm.image_factor == 32
+    words, ids = [], g["input_ids"][0].tolist()
+    i = 0
+    while i < len(ids):
+        if ids[i] == cfg["image_token_id"]:
+            words.append("<|image_pad|>")
+            while i < len(ids) and ids[i] == cfg["image_token_id"]:
+                i += 1
+            continue
+        words.append({cfg["vision_start_token_id"]: "<|vision_start|>", cfg["vision_end_token_id"]: "<|vision_end|>"}.get(ids[i], f"w{ids[i]}"))
+        i += 1
+    n_new = g["f32_step_logits"].shape[1]
+    sp = SamplingParams(temperature=0.0, max_tokens=n_new, stop_token_ids=[])
+    outs = llm.generate([{"prompt": " ".join(words), "multi_modal_data": {"image": torch.from_numpy(g["frames"])}}], sampling_params=sp)
+    assert outs[0].prompt_token_ids == ids
+    assert outs[0].outputs[0].token_ids == g["bf16_ids"][0, len(ids):].tolist()
