@@ -139,6 +139,12 @@ int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* 
 int o3v_linear_decode_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale, const void* bias,
                           const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
                           o3v_stream_t stream);
+/* fp8 rows for 4 <= M <= 32 rows of already normalised x (batched decode, N = 16 self-consistency chains of BASELINE config #5):
+ * W8p is the fragment-major fp8 image [N/16][K/64][64][16 B] of the matrix; the weights are widened exactly to bf16 in registers
+ * and multiplied on the bf16 matrix cores, the row scale multiplies the fp32 sum.  Epilogues NONE / RESIDUAL / SWIGLU.
+ * K % 64 == 0, N % 16 == 0 (SWIGLU: N % 32 == 0). */
+int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res, void* out,
+                               int M, int N, int K, int ldx, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,
                                const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT, void* qout,
                                void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row,
@@ -273,6 +279,9 @@ typedef struct {
     /* Qwen3-VL (TF3:438-500): RMSNorm weights [D] applied per head to q and k before the rotation; NULL = none (Qwen2.5-VL).
      * With them qkv_b is NULL (attention_bias false) and the decode runs q/k/v as linear + o3v_qkv_norm_rope_cache. */
     const void *q_norm, *k_norm;
+    /* optional fragment-major fp8 images [N/16][K/64][64][16 B] of the four matrices (same scales): 4..32 decode rows stream
+     * these (o3v_linear_decode_fp8_rows); q/k/v only without the fused rotation (Qwen3-VL) */
+    const void *qkv_w8p, *o_w8p, *gu_w8p, *down_w8p;
 } o3v_llm_layer_w;
 
 typedef struct {
@@ -286,6 +295,7 @@ typedef struct {
     int gemm_tile;               /* 0 = per shape; 128 / 256 = force that GEMM kernel in the prefill (tests) */
     const void* lm_head8;        /* optional fp8 copy of lm_head + per-row scales (decode, <= 3 rows) */
     const float* lm_head_s;
+    const void* lm_head8p;       /* optional fragment-major fp8 image of lm_head (4..32 rows) */
 } o3v_llm_desc;
 
 size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P);

@@ -30,7 +30,8 @@ class VitDesc(C.Structure):
 
 class LlmLayerW(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1", "ln2", "qkv_w", "qkv_b", "o_w", "gu_w", "down_w", "qkv_wp", "o_wp", "gu_wp", "down_wp",
-                                  "qkv_w8", "o_w8", "gu_w8", "down_w8", "qkv_s", "o_s", "gu_s", "down_s", "q_norm", "k_norm")]
+                                  "qkv_w8", "o_w8", "gu_w8", "down_w8", "qkv_s", "o_s", "gu_s", "down_s", "q_norm", "k_norm",
+                                  "qkv_w8p", "o_w8p", "gu_w8p", "down_w8p")]
 
 
 class Vit3BlockW(C.Structure):
@@ -52,7 +53,7 @@ class Vit3Desc(C.Structure):
 class LlmDesc(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32), ("head_dim", i32), ("inter", i32),
                 ("vocab", i32), ("rms_eps", f32), ("embed", vp), ("layer", C.POINTER(LlmLayerW)), ("final_norm", vp),
-                ("lm_head", vp), ("lm_head_p", vp), ("gemm_tile", i32), ("lm_head8", vp), ("lm_head_s", vp)]
+                ("lm_head", vp), ("lm_head_p", vp), ("gemm_tile", i32), ("lm_head8", vp), ("lm_head_s", vp), ("lm_head8p", vp)]
 
 
 class DecodeState(C.Structure):
@@ -107,6 +108,7 @@ SIGNATURES = {
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_linear_decode_fp8_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_norm_qkv_rope_fp8": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

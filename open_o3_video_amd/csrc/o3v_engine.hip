@@ -319,6 +319,11 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
                             o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
+    if (rows >= 4 && rows <= 32 && d->lm_head8p) {  // batched decode on fp8 rows: norm apart, fp8 fragments widened in registers
+        TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
+        return o3v_linear_decode_fp8_rows(normed, d->lm_head8p, d->lm_head_s, nullptr, nullptr, logits, rows, d->vocab, H, H, d->vocab, 0,
+                                          O3V_EPI_NONE, s);
+    }
     if (rows >= 8 && rows <= 32 && d->lm_head_p) {  // batched decode: norm apart, LDS-free matrix-core linear
         TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
         return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
@@ -372,6 +377,9 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
     // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
     const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
+    // fp8 rows at 4..32 rows (BASELINE config #5: N = 16 chains on fp8 weights): norms run apart, the linears stream the
+    // fragment-major fp8 images (q/k/v only where the rotation is not fused into the linear, i.e. Qwen3-VL)
+    const bool fp8b = B >= 4 && d->layer[0].gu_w8p && d->layer[0].down_w8p && d->layer[0].o_w8p;
     const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
     bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
     int step = step0;
@@ -384,7 +392,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             if (fp8)
                 TRY(o3v_linear_decode_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
                                           O3V_EPI_NONE, s));
-            else if (norm_apart) {  // (above 16 rows the linears take no fused norm at all)
+            else if (fp8b && lw.qkv_w8p) {
+                TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+                TRY(o3v_linear_decode_fp8_rows(w.h, lw.qkv_w8p, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
+            } else if (norm_apart) {  // (above 16 rows the linears take no fused norm at all)
                 TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
             } else
@@ -413,6 +424,8 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                 st->nsplit, scale, s));
         if (fp8)
             TRY(o3v_linear_decode_fp8(w.att, nullptr, 0.f, lw.o_w8, lw.o_s, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        else if (fp8b)
+            TRY(o3v_linear_decode_fp8_rows(w.att, lw.o_w8p, lw.o_s, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
         else
             TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
         return O3V_OK;
@@ -460,6 +473,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                           O3V_EPI_SWIGLU, s));
                 TRY(o3v_linear_decode_fp8(w.mlp, nullptr, 0.f, lw.down_w8, lw.down_s, nullptr, st->x, st->x, B, H, I, I, H, H,
                                           O3V_EPI_RESIDUAL, s));
+                continue;
+            }
+            if (fp8b) {
+                TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
+                TRY(o3v_linear_decode_fp8_rows(w.h, lw.gu_w8p, lw.gu_s, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0, O3V_EPI_SWIGLU, s));
+                TRY(o3v_linear_decode_fp8_rows(w.mlp, lw.down_w8p, lw.down_s, nullptr, st->x, st->x, B, H, I, I, H, H, O3V_EPI_RESIDUAL, s));
                 continue;
             }
             if (norm_apart) {

@@ -650,6 +650,171 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same skinny GEMM on fp8 (OCP e4m3fn) weight rows with one fp32 scale per output row (BASELINE config #5: N = 16
+// self-consistency chains on fp8 weights), 4 <= M <= 32 rows of already normalised x.  The weights travel as fp8 -- half the
+// bytes of the stream that bounds the kernel -- and are widened EXACTLY to bf16 in registers (v_cvt_scalef32_pk_bf16_fp8: 3
+// mantissa bits fit in 7), so the arithmetic is the bf16 MFMA of the kernel above on the dequantised values and the row scale
+// multiplies the finished fp32 sum; activations, accumulation and epilogues are unchanged (an fp8 x fp8 MFMA would have to round
+// x to fp8 as well).  W8p: fragment-major image [N/16][K/64][64 lanes][16 B] (weights.py pack_mfma_fragments_fp8): lane
+// (row = lane & 15, g = lane >> 4) of (row block, 64-wide double step t) holds W[row][64 t + 16 g .. + 16), i.e. the A fragments
+// of two MFMAs, whose B fragments are x[m][64 t + 16 g + {0..7}, {8..15}] -- the k order differs from the bf16 kernel's, the set
+// does not.  One contiguous KiB per wave-instruction.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int KS, int CB>
+__global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __restrict__ X, const uint8_t* __restrict__ W8p,
+                                                            const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
+                                                            const bf16_t* __restrict__ res, bf16_t* __restrict__ out, int M, int N,
+                                                            int K, int ldx, int ldo, int ldr) {
+    constexpr int RB = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RG = 4 / KS;
+    constexpr int U = RB == 1 ? 4 : 2;  // double steps per trip: 4 KiB of weights in flight per buffer and wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [KS > 1: 4 x RB x CB x 64 x 4 f32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rg = wave / KS, ks = wave % KS;
+    const int grp = blockIdx.x * RG + rg;
+    int rb0[RB];
+    if (EPI == EPI_SWIGLU) {
+        rb0[0] = grp * 32;
+        rb0[RB - 1] = grp * 32 + 16;
+    } else {
+        rb0[0] = grp * 16;
+    }
+    const int nt = K >> 6;  // 64-wide double steps
+    const u32x4* wrow[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int blk = (rb0[b] < N ? rb0[b] : 0) >> 4;
+        wrow[b] = reinterpret_cast<const u32x4*>(W8p) + (size_t)blk * nt * 64 + lane;
+    }
+    const int per = (nt + KS - 1) / KS;
+    const int t_begin = ks * per;
+    int t_end = t_begin + per;
+    t_end = t_end < nt ? t_end : nt;
+
+    float e_scale[RB][4], e_bias[RB][4], e_res[CB][4];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n = rb0[b] + fg * 4 + r;
+            n = n < N ? n : N - 1;
+            e_scale[b][r] = wscale[n];
+            e_bias[b][r] = bias ? bf2f(bias[n]) : 0.f;
+        }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int m = fr + 16 * cb < M ? fr + 16 * cb : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n = rb0[0] + fg * 4 + r;
+            n = n < N ? n : N - 1;
+            e_res[cb][r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
+        }
+    }
+    f32x4 acc[RB][CB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[b][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 wf0[U][RB], wf1[U][RB];
+    bf16x8 xf0[U][CB][2], xf1[U][CB][2];
+    auto load_w = [&](u32x4 (&wf)[U][RB], bf16x8 (&xf)[U][CB][2], int t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < t_end) {  // wave-uniform
+#pragma unroll
+                for (int b = 0; b < RB; ++b) wf[u][b] = __builtin_nontemporal_load(wrow[b] + (size_t)t * 64);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const bool has = fr + 16 * cb < M;
+                    const bf16_t* xp = X + (size_t)(fr + 16 * cb) * ldx + t * 64 + fg * 16;
+                    xf[u][cb][0] = has ? *reinterpret_cast<const bf16x8*>(xp) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    xf[u][cb][1] = has ? *reinterpret_cast<const bf16x8*>(xp + 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < RB; ++b) wf[u][b] = (u32x4){0u, 0u, 0u, 0u};  // fp8 zero: widens to 0.0
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) xf[u][cb][0] = xf[u][cb][1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    auto widen = [](uint32_t lo, uint32_t hi) -> bf16x8 {  // 8 fp8 -> 8 bf16, k order preserved
+        const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+        const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+        const u32x4 p = {__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c),
+                         __builtin_bit_cast(uint32_t, d)};
+        return __builtin_bit_cast(bf16x8, p);
+    };
+    auto compute = [&](u32x4 (&wf)[U][RB], bf16x8 (&xf)[U][CB][2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const bf16x8 a0 = widen(wf[u][b][0], wf[u][b][1]), a1 = widen(wf[u][b][2], wf[u][b][3]);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, xf[u][cb][0], acc[b][cb], 0, 0, 0);
+                    acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, xf[u][cb][1], acc[b][cb], 0, 0, 0);
+                }
+            }
+    };
+    load_w(wf0, xf0, t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += 2 * U) {
+        load_w(wf1, xf1, t0 + U);
+        compute(wf0, xf0);
+        load_w(wf0, xf0, t0 + 2 * U);
+        compute(wf1, xf1);
+    }
+    if (KS > 1) {
+        f32x4* part = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) part[((wave * RB + b) * CB + cb) * 64 + lane] = acc[b][cb];
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k2 = 0; k2 < KS; ++k2) t += part[(((rg * KS + k2) * RB + b) * CB + cb) * 64 + lane];
+                acc[b][cb] = t;
+            }
+    }
+    // ---- epilogue: this lane holds C[n = rb0 + 4*fg + r][m = fr + 16 cb]; the row scale multiplies the fp32 sum first
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int m = fr + 16 * cb;
+        if (m >= M) continue;
+        if (EPI == EPI_SWIGLU) {
+            const int no0 = grp * 16 + fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int no = no0 + r;
+                if (no >= (N >> 1)) continue;
+                const float g = rbf(acc[0][cb][r] * e_scale[0][r] + e_bias[0][r]);
+                const float u = rbf(acc[RB - 1][cb][r] * e_scale[RB - 1][r] + e_bias[RB - 1][r]);
+                out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rb0[0] + fg * 4 + r;
+                if (n >= N) continue;
+                float v = acc[0][cb][r] * e_scale[0][r] + e_bias[0][r];
+                if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[cb][r];
+                out[(size_t)m * ldo + n] = f2bf(v);
+            }
+        }
+    }
+}
+
 struct GemvArgs {
     const bf16_t *X, *W, *bias, *res, *norm_w;
     bf16_t* out;
@@ -1079,6 +1244,51 @@ extern "C" int o3v_linear_decode_fp8(const void* X, const void* norm_w, float ep
                                      int ldr, int epilogue, hipStream_t stream) {
     if (!scale) return O3V_ERR_ARG;
     return gemv_dispatch(X, W8, bias, res, out, norm_w, eps, M, N, K, ldx, K, ldo, ldr, epilogue, stream, nullptr, nullptr, scale);
+}
+
+// fp8 rows at 4..32 rows of x (already normalised): the matrix-core kernel above on the fragment-major fp8 image W8p.
+// epilogue NONE / RESIDUAL / SWIGLU (W8p then packs the interleaved gate/up matrix), K % 64 == 0, N % 16 == 0.
+extern "C" int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res,
+                                          void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue, hipStream_t stream) {
+    if (!X || !W8p || !scale || !out || M < 4 || M > 32 || N <= 0 || K <= 0) return O3V_ERR_ARG;
+    if ((K & 63) || (N & 15) || (ldx & 7) || (epilogue == EPI_SWIGLU && (N & 31))) return O3V_ERR_SHAPE;
+    if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
+    const int RB = epilogue == EPI_SWIGLU ? 2 : 1;
+    const int groups = epilogue == EPI_SWIGLU ? N / 32 : N / 16;
+    const int ks = groups >= 2048 ? 1 : 4;  // as the bf16 kernel: >= 8 waves per CU
+    const int cbn = M > 16 ? 2 : 1;
+#define O3V_F8K(E, KK, CC)                                                                                                       \
+    do {                                                                                                                         \
+        constexpr int RG_ = 4 / KK;                                                                                              \
+        const dim3 grid((groups + RG_ - 1) / RG_), block(256);                                                                   \
+        const size_t sh = KK > 1 ? (size_t)4 * RB * CC * 64 * 16 : 0;                                                            \
+        O3V_KLAUNCH((gemv_mfma_fp8_kernel<E, KK, CC>), grid, block, sh, stream, (const bf16_t*)X, (const uint8_t*)W8p, scale,    \
+                    (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, ldx, ldo, ldr);                              \
+    } while (0)
+#define O3V_F8E(E)                       \
+    do {                                 \
+        if (ks == 1) {                   \
+            if (cbn == 2)                \
+                O3V_F8K(E, 1, 2);        \
+            else                         \
+                O3V_F8K(E, 1, 1);        \
+        } else {                         \
+            if (cbn == 2)                \
+                O3V_F8K(E, 4, 2);        \
+            else                         \
+                O3V_F8K(E, 4, 1);        \
+        }                                \
+    } while (0)
+    switch (epilogue) {
+        case EPI_NONE: O3V_F8E(EPI_NONE); break;
+        case EPI_RESIDUAL: O3V_F8E(EPI_RESIDUAL); break;
+        case EPI_SWIGLU: O3V_F8E(EPI_SWIGLU); break;
+        default: return O3V_ERR_ARG;
+    }
+#undef O3V_F8E
+#undef O3V_F8K
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
 }
 
 extern "C" int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,

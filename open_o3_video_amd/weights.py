@@ -46,6 +46,15 @@ def pack_mfma_fragments(w: torch.Tensor) -> torch.Tensor:
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+def pack_mfma_fragments_fp8(w8: torch.Tensor) -> torch.Tensor:
+    """uint8 [N,K] (fp8 codes, row-major) -> fragment-major [N/16][K/64][64 lanes][16]: lane l of (row block nb, 64-wide double
+    step t) holds W[nb*16 + (l & 15)][t*64 + (l >> 4)*16 : +16] -- the A fragments of two MFMAs, one contiguous KiB per
+    wave-instruction (csrc/o3v_gemm.hip gemv_mfma_fp8_kernel).  Requires N % 16 == 0 and K % 64 == 0."""
+    N, K = w8.shape
+    assert N % 16 == 0 and K % 64 == 0
+    return w8.view(N // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
 FP8_MAX = 448.0   # largest finite OCP e4m3fn value
 
 
@@ -152,6 +161,9 @@ class DeviceWeights:
                     keep[f"l{i}.{f}8"], keep[f"l{i}.{f}8s"] = q8, sc
                     setattr(self.llm_layers[i], f[:-1] + "w8", q8.data_ptr())
                     setattr(self.llm_layers[i], f[:-2] + "_s", sc.data_ptr())
+                    if batched_decode and q8.shape[0] % 16 == 0 and q8.shape[1] % 64 == 0:
+                        keep[f"l{i}.{f}8p"] = pack_mfma_fragments_fp8(q8)       # 4..32 decode rows (config #5's N = 16 chains)
+                        setattr(self.llm_layers[i], f[:-1] + "w8p", keep[f"l{i}.{f}8p"].data_ptr())
         keep["l.norm"] = l("norm.weight").contiguous()
         if tc.tie_word_embeddings:
             keep["l.head"] = keep["l.embed"]
@@ -173,6 +185,9 @@ class DeviceWeights:
         if fp8_decode:
             keep["l.head8"], keep["l.head8s"] = quantize_rows_fp8(keep["l.head"])
             self.llm.lm_head8, self.llm.lm_head_s = keep["l.head8"].data_ptr(), keep["l.head8s"].data_ptr()
+            if batched_decode and keep["l.head8"].shape[0] % 16 == 0 and keep["l.head8"].shape[1] % 64 == 0:
+                keep["l.head8p"] = pack_mfma_fragments_fp8(keep["l.head8"])
+                self.llm.lm_head8p = keep["l.head8p"].data_ptr()
         self._check_shapes()
 
     def _pack_vision(self, v):

@@ -458,6 +458,41 @@ def test_qkv_rope_cache_two_column_blocks(dev, M, Hq, Hkv, D, K):
     assert (k2[:, :, :slot] == 0).all() and (k2[:, :, slot + 1:] == 0).all()
 
 
+@pytest.mark.parametrize("M", [4, 8, 16, 21, 32])
+@pytest.mark.parametrize("N,K,epi_name", [(37888, 3584, "swiglu"), (3584, 18944, "res"), (6144, 4096, "none"), (4096, 4096, "res"),
+                                          (24576, 4096, "swiglu"), (8192, 1024, "none"), (128, 64, "none")])
+def test_linear_decode_fp8_rows(dev, M, N, K, epi_name):
+    """o3v_linear_decode_fp8_rows (4..32 rows of x against fp8 rows + per-row scales, fragment-major image, widened exactly to
+    bf16 and multiplied on the matrix cores) against the bf16 kernels run on the DEQUANTISED weights (exact in bf16: power-of-two
+    scales) and the fp32 reference: same values, another summation order."""
+    import ctypes as C
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import dequantize_rows_fp8, pack_mfma_fragments_fp8, quantize_rows_fp8
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, generator=g) * 2).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    q8, sc = quantize_rows_fp8(w)
+    wq = dequantize_rows_fp8(q8, sc).to(BF)
+    assert torch.equal(wq.float(), dequantize_rows_fp8(q8, sc))       # exact in bf16
+    q8p = pack_mfma_fragments_fp8(q8)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    epi = {"none": ops.EPI_NONE, "swiglu": ops.EPI_SWIGLU, "res": ops.EPI_RESIDUAL}[epi_name]
+    No = N // 2 if epi == ops.EPI_SWIGLU else N
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty(M, No, dtype=BF, device=dev)
+    _lib.call("o3v_linear_decode_fp8_rows", P(x), P(q8p), P(sc), P(bias), P(res) if epi == ops.EPI_RESIDUAL else None, P(out), M, N, K, K,
+              No, N, epi, st)
+    if epi == ops.EPI_SWIGLU:
+        ref = ops.gemm(x, wq, bias, None, epi, force="gemm")
+        close_bf16(out, ref.float(), ulps=1, atol=1e-3, frac=0.998)
+    else:
+        close_bf16(out, _epi_ref(x.float() @ wq.float().t(), bias, res if epi == ops.EPI_RESIDUAL else None, epi))
+    assert _lib.load().o3v_linear_decode_fp8_rows(P(x), P(q8p), P(sc), None, None, P(out), 3, N, K, K, No, N, ops.EPI_NONE, st) == _lib.ERR_ARG
+
+
 def test_gemm_rejects_bad_shapes(dev):
     import kernel_ops as ops
     from open_o3_video_amd import _lib

@@ -162,6 +162,17 @@ def test_q3_fp8_decode_rows(need_gpu, golden_dir):
         k += 1
     print(f"q3 fp8 rows: bf16 {ga} fp8 {gb} margins {np.round(m, 3).tolist()}")
     assert k == 10 or m[k] < 2 * LOGIT_ATOL
+    # 4..32 rows: the fragment-major fp8 images on the matrix cores (N chains of one question, BASELINE config #5)
+    assert e2.w.llm.layer[0].gu_w8p and e2.w.llm.lm_head8p
+    for G in (4, 16, 20):
+        c1 = e1.generate(g["input_ids"], None, num_return_sequences=G, **kw)
+        c2 = e2.generate(g["input_ids"], None, num_return_sequences=G, **kw)
+        r1, r2, mm = c1.sequences[G - 1, -10:].tolist(), c2.sequences[G - 1, -10:].tolist(), c1.margins[G - 1].tolist()
+        k = 0
+        while k < 10 and r1[k] == r2[k]:
+            k += 1
+        print(f"q3 fp8 rows, {G} rows: follow the bf16 rows for {k}/10 tokens")
+        assert k == 10 or mm[k] < 2 * LOGIT_ATOL, (G, k, mm[k])
 
 
 def test_q3_through_the_hf_facade(need_gpu, golden_dir):
