@@ -268,6 +268,6 @@ Qwen2VLForConditionalGeneration = Qwen2_5_VLForConditionalGeneration
 
 
 class Qwen3VLForConditionalGeneration(Qwen2_5_VLForConditionalGeneration):
-    """The same surface over a Qwen3-VL checkpoint (BASELINE config #5's scorer, R:README.md:29,37): `config.json` with
+    """The same surface over a Qwen3-VL checkpoint (BASELINE config #5's base model, R:README.md:37): `config.json` with
     model_type qwen3_vl selects the Qwen3-VL tower, DeepStack and q/k norm inside the engine; either class name loads either
     family."""

@@ -1,4 +1,4 @@
-"""Oracle for the Qwen3-VL family (BASELINE config #5's scorer model): forward + generate restated op-by-op on torch-CPU.
+"""Oracle for the Qwen3-VL family (BASELINE config #5's base model): forward + generate restated op-by-op on torch-CPU.
 
 No ``transformers`` import.  Cites TF3 = transformers 5.15.0 ``models/qwen3_vl/modeling_qwen3_vl.py`` (third-party; the
 reference uses Qwen3-VL-8B through vLLM, R:README.md:29,37, R:eval/test/test_videomme.py:129-226).  What differs from the
