@@ -82,7 +82,7 @@ class Qwen2_5_VLForConditionalGeneration:
 
     # ---- construction
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=None, attn_implementation=None, use_cache=True, device="cuda", **_):
+    def from_pretrained(cls, path, torch_dtype=None, attn_implementation=None, use_cache=True, device="cuda", fp8_decode=False, **_):
         """Local checkpoint directory only (config.json + *.safetensors).  `attn_implementation` is accepted and
         ignored: attention always runs in the hand-written HIP kernels."""
         if not os.path.isdir(path):
@@ -90,7 +90,7 @@ class Qwen2_5_VLForConditionalGeneration:
         if torch_dtype not in (None, torch.bfloat16, "bfloat16", "auto"):
             raise ValueError("the MI355X path computes in bf16 (torch_dtype=torch.bfloat16)")
         cfg = O3VConfig.from_pretrained(path)
-        w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device)
+        w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device, fp8_decode=bool(fp8_decode))
         model = cls(cfg, O3VEngine(cfg, w))
         gc = load_generation_config(path)
         if gc:

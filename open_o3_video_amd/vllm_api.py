@@ -65,7 +65,7 @@ class LLM:
                  gpu_memory_utilization: float = 0.9, limit_mm_per_prompt: Optional[dict] = None, dtype: str = "bfloat16",
                  max_num_seqs: int = 8, engine: Optional[O3VEngine] = None, tokenizer: Any = None,
                  min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda",
-                 enable_prefix_caching: bool = True, **_):
+                 enable_prefix_caching: bool = True, quantization: Optional[str] = None, **_):
         if tensor_parallel_size != 1:
             raise ValueError("the reference runs tensor_parallel_size=1 (R:eval/models/model_vllm.py:21); data parallelism "
                              "is one engine per GPU (open_o3_video_amd.dist)")
@@ -75,7 +75,11 @@ class LLM:
             if model is None or not os.path.isdir(model):
                 raise OSError(f"{model} is not a local checkpoint directory (this build never downloads)")
             cfg = O3VConfig.from_pretrained(model)
-            engine = O3VEngine(cfg, DeviceWeights(cfg, getter_from_safetensors_dir(model), device))
+            # vLLM's keyword: quantization="fp8" quantises the bf16 checkpoint's linears on load (here: fp8 e4m3fn decode rows with
+            # one power-of-two scale per output row beside the bf16 matrices, which prefill keeps using; BASELINE config #5)
+            if quantization not in (None, "fp8"):
+                raise ValueError(f"quantization={quantization!r}: only None or 'fp8' (decode rows) is built")
+            engine = O3VEngine(cfg, DeviceWeights(cfg, getter_from_safetensors_dir(model), device, fp8_decode=quantization == "fp8"))
             tokenizer = tokenizer or _load_tokenizer(model)
             pp = os.path.join(model, "preprocessor_config.json")
             if os.path.exists(pp):

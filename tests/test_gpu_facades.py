@@ -96,6 +96,12 @@ def test_from_pretrained_local_dir_with_hub_names(need_gpu, tmp_path, golden_dir
     assert np.array_equal(out.cpu().numpy(), g["bf16_ids"])
     with pytest.raises(OSError):
         Qwen2_5_VLForConditionalGeneration.from_pretrained("Qwen/Qwen2.5-VL-7B-Instruct")  # never downloads
+    # vLLM's quantization="fp8": fp8 decode rows are built on load from the bf16 checkpoint
+    from open_o3_video_amd.vllm_api import LLM
+    llm = LLM(model=str(tmp_path), tokenizer=StubTokenizer(cfg), quantization="fp8")
+    assert llm.engine.w.fp8_decode and llm.engine.w.llm.lm_head8
+    with pytest.raises(ValueError):
+        LLM(model=str(tmp_path), tokenizer=StubTokenizer(cfg), quantization="awq")
 
 
 def test_vllm_facade(need_gpu, golden_dir):
