@@ -339,6 +339,17 @@ int o3v_vit3_forward(const o3v_vit3_desc* d, const void* pixels, int P, const vo
                      const float* sinT, const int* tiles, int n_tiles, void* workspace, size_t ws_bytes, void* out, void* deep_out,
                      o3v_stream_t stream);
 
+/* ---- context handle: the library keeps NO mutable state of its own; a context is an owning host-side copy of
+ * the model descriptors (the structs above with their block / layer arrays; the device buffers they point at stay the
+ * caller's), so that an FFI caller can drop its own structs after create.  Any descriptor may be NULL.  Host code only: no
+ * HIP call, usable without a GPU.  The model-level entries take the descriptor pointers the accessors return. */
+typedef struct o3v_ctx o3v_ctx;
+o3v_ctx* o3v_ctx_create(const o3v_llm_desc* llm, const o3v_vit_desc* vit, const o3v_vit3_desc* vit3);
+void o3v_ctx_destroy(o3v_ctx* ctx);
+const o3v_llm_desc* o3v_ctx_llm(const o3v_ctx* ctx);
+const o3v_vit_desc* o3v_ctx_vit(const o3v_ctx* ctx);
+const o3v_vit3_desc* o3v_ctx_vit3(const o3v_ctx* ctx);
+
 size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows);
 /* Qwen2_5_VLTextModel.forward over the prompt, TF:790-872: x bf16 [B*S,H] holds inputs_embeds on entry and the
  * last layer's residual stream on return; K/V caches [layers][B][Hkv][Tmax][D].

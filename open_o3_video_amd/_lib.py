@@ -74,6 +74,11 @@ class PrefillOpts(C.Structure):
 # name -> argtypes (return type int unless listed in _RET)
 SIGNATURES = {
     "o3v_abi_version": [],
+    "o3v_ctx_create": [C.POINTER(LlmDesc), C.POINTER(VitDesc), C.POINTER(Vit3Desc)],
+    "o3v_ctx_destroy": [vp],
+    "o3v_ctx_llm": [vp],
+    "o3v_ctx_vit": [vp],
+    "o3v_ctx_vit3": [vp],
     "o3v_rmsnorm": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "o3v_layernorm": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "o3v_qkv_norm_rope_cache": [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -130,7 +135,8 @@ SIGNATURES = {
     "o3v_llm_head": [C.POINTER(LlmDesc), vp, i32, i32, vp, vp, vp],
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }
-_RET = {"o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
+_RET = {"o3v_ctx_create": vp, "o3v_ctx_destroy": None, "o3v_ctx_llm": C.POINTER(LlmDesc), "o3v_ctx_vit": C.POINTER(VitDesc),
+        "o3v_ctx_vit3": C.POINTER(Vit3Desc), "o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
 
 SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
 SAMPLE_SCRATCH_FLOATS = 40960   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h

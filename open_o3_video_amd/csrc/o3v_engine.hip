@@ -52,6 +52,51 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 extern "C" int o3v_abi_version(void) { return 5; }
 
+// ------------------------------------------------------------------------------------------------ context handle
+// Owning host-side copy of the descriptors ("no global mutable state except an explicit o3v_ctx").
+#include <new>
+#include <vector>
+struct o3v_ctx {
+    bool has_llm = false, has_vit = false, has_vit3 = false;
+    o3v_llm_desc llm{};
+    o3v_vit_desc vit{};
+    o3v_vit3_desc vit3{};
+    std::vector<o3v_llm_layer_w> layers;
+    std::vector<o3v_vit_block_w> blocks;
+    std::vector<o3v_vit3_block_w> blocks3;
+};
+
+extern "C" o3v_ctx* o3v_ctx_create(const o3v_llm_desc* llm, const o3v_vit_desc* vit, const o3v_vit3_desc* vit3) {
+    if ((llm && (llm->layers < 0 || (llm->layers > 0 && !llm->layer))) || (vit && (vit->depth < 0 || (vit->depth > 0 && !vit->blocks))) ||
+        (vit3 && (vit3->depth < 0 || (vit3->depth > 0 && !vit3->blocks))))
+        return nullptr;
+    o3v_ctx* c = new (std::nothrow) o3v_ctx();
+    if (!c) return nullptr;
+    if (llm) {
+        c->has_llm = true;
+        c->llm = *llm;
+        c->layers.assign(llm->layer, llm->layer + llm->layers);
+        c->llm.layer = c->layers.data();
+    }
+    if (vit) {
+        c->has_vit = true;
+        c->vit = *vit;
+        c->blocks.assign(vit->blocks, vit->blocks + vit->depth);
+        c->vit.blocks = c->blocks.data();
+    }
+    if (vit3) {
+        c->has_vit3 = true;
+        c->vit3 = *vit3;
+        c->blocks3.assign(vit3->blocks, vit3->blocks + vit3->depth);
+        c->vit3.blocks = c->blocks3.data();
+    }
+    return c;
+}
+extern "C" void o3v_ctx_destroy(o3v_ctx* ctx) { delete ctx; }
+extern "C" const o3v_llm_desc* o3v_ctx_llm(const o3v_ctx* ctx) { return ctx && ctx->has_llm ? &ctx->llm : nullptr; }
+extern "C" const o3v_vit_desc* o3v_ctx_vit(const o3v_ctx* ctx) { return ctx && ctx->has_vit ? &ctx->vit : nullptr; }
+extern "C" const o3v_vit3_desc* o3v_ctx_vit3(const o3v_ctx* ctx) { return ctx && ctx->has_vit3 ? &ctx->vit3 : nullptr; }
+
 // ------------------------------------------------------------------------------------------------ ViT
 extern "C" size_t o3v_vit_workspace_bytes(const o3v_vit_desc* d, int P) {
     if (!d || P <= 0) return 0;

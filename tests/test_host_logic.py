@@ -256,3 +256,31 @@ def test_qwen3vl_vision_head_padding_layout():
     want = rot(q, np.cos(ang), np.sin(ang), half)
     got = rot(qp, cos, sin, halfp)
     assert np.allclose(got[:, valid], want[:, src[valid]]) and np.allclose(got[:, ~valid], 0.0)
+
+
+def test_ctx_handle_owns_descriptor_copies():
+    """o3v_ctx_create / destroy (host only, no GPU): the context deep-copies the descriptors and their layer arrays, so the caller's
+    structs may go away; accessors hand back what the model-level entries take."""
+    import ctypes as C
+    lib = _lib.load()
+    layers = (_lib.LlmLayerW * 3)()
+    for i in range(3):
+        layers[i].ln1 = 1000 + i
+        layers[i].qkv_w = 2000 + i
+    d = _lib.LlmDesc(hidden=64, layers=3, heads=2, kv_heads=1, head_dim=32, inter=128, vocab=100, rms_eps=1e-6, layer=layers, embed=77)
+    blocks = (_lib.VitBlockW * 2)()
+    blocks[1].qkv_w = 4242
+    v = _lib.VitDesc(depth=2, hidden=64, heads=2, blocks=blocks)
+    ctx = lib.o3v_ctx_create(C.byref(d), C.byref(v), None)
+    assert ctx
+    layers[1].ln1 = 0            # the caller's copies change / disappear
+    d.hidden = 0
+    del blocks, v
+    got = lib.o3v_ctx_llm(ctx).contents
+    assert got.hidden == 64 and got.layers == 3 and got.embed == 77 and got.layer[1].ln1 == 1001 and got.layer[2].qkv_w == 2002
+    assert lib.o3v_ctx_vit(ctx).contents.blocks[1].qkv_w == 4242
+    assert not lib.o3v_ctx_vit3(ctx)
+    lib.o3v_ctx_destroy(ctx)
+    lib.o3v_ctx_destroy(None)
+    bad = _lib.LlmDesc(layers=2)              # layers without a layer array
+    assert not lib.o3v_ctx_create(C.byref(bad), None, None)
