@@ -11,7 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from open_o3_video_amd import _lib, indexing, ops  # noqa: E402
+from open_o3_video_amd import _lib, indexing  # noqa: E402
+import kernel_ops as ops  # noqa: E402  (tests/kernel_ops.py: thin ctypes wrappers of the C ABI)
 from test_gpu_kernels import _attn_ref, _epi_ref, close_bf16  # noqa: E402
 
 BF = torch.bfloat16
@@ -19,7 +20,7 @@ dev = torch.device("cuda")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
-t0, n = time.time(), {"gemm": 0, "gemv": 0, "attn": 0, "prefill_attn": 0}
+t0, n = time.time(), {"gemm": 0, "gemv": 0, "fp8_rows": 0, "attn": 0, "prefill_attn": 0}
 while time.time() - t0 < budget:
     # ---- GEMM (both tilings, launcher's choice included)
     M, N, K = ri(1, 900), 8 * ri(1, 200), 64 * ri(1, 12)
@@ -37,14 +38,29 @@ while time.time() - t0 < budget:
     if M <= 128:
         close_bf16(ops.gemm_splitk(a, w, b, r, epi, ri(1, 9)), _epi_ref(acc, b, r, epi))
     n["gemm"] += 1
-    # ---- skinny GEMM / GEMV, 1..16 rows
-    M, N, K = ri(1, 16), 16 * ri(1, 300), 32 * ri(1, 64)
+    # ---- skinny GEMM / GEMV, 1..32 rows (17..32: two MFMA column blocks)
+    M, N, K = ri(1, 32), 16 * ri(1, 300), 32 * ri(1, 64)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
     res = torch.randn(M, N, generator=g).to(BF).to(dev)
     acc = a.float() @ w.float().t()
     close_bf16(ops.gemm(a, w, None, res, ops.EPI_RESIDUAL, force="gemv"), _epi_ref(acc, None, res, ops.EPI_RESIDUAL))
     n["gemv"] += 1
+    # ---- fp8 rows at 4..32 rows (fragment-major image, exact widening) vs fp32 on the dequantised weights
+    from open_o3_video_amd.weights import dequantize_rows_fp8, pack_mfma_fragments_fp8, quantize_rows_fp8
+    import ctypes as C
+    M, N, K = ri(4, 32), 16 * ri(1, 200), 64 * ri(1, 40)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    q8, sc = quantize_rows_fp8(w)
+    q8p = pack_mfma_fragments_fp8(q8)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    o8 = torch.empty(M, N, dtype=BF, device=dev)
+    P_ = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _lib.call("o3v_linear_decode_fp8_rows", P_(a), P_(q8p), P_(sc), None, P_(res), P_(o8), M, N, K, K, N, N, ops.EPI_RESIDUAL,
+              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    close_bf16(o8, _epi_ref(a.float() @ dequantize_rows_fp8(q8, sc).t(), None, res, ops.EPI_RESIDUAL))
+    n["fp8_rows"] += 1
     # ---- decode attention: per-row and group forms
     G, groups, Hkv, rep = ri(2, 8), ri(1, 2), ri(1, 4), ri(1, 7)
     B, Hq, D = G * groups, Hkv * rep, 128
@@ -69,6 +85,12 @@ while time.time() - t0 < budget:
         grp = ops.attn_decode_group(q.to(dev), k.to(dev), v.to(dev), pads.to(dev), G, P, ctx, nsp if G * rep <= 64 else -abs(nsp),
                                     D ** -0.5).cpu()
         close_bf16(grp, std, ulps=3, atol=4e-3)
+        # the same with the prompts' K/V kept once and the rows' caches holding only their own keys: bit-identical
+        kpre, vpre = k[::G, :, :P].contiguous(), v[::G, :, :P].contiguous()
+        kown, vown = k[:, :, P:].contiguous(), v[:, :, P:].contiguous()
+        grp2 = ops.attn_decode_group_prefix(q.to(dev), kown.to(dev), vown.to(dev), kpre.to(dev), vpre.to(dev), G, pads.to(dev), G, P, ctx,
+                                            nsp if G * rep <= 64 else -abs(nsp), D ** -0.5).cpu()
+        assert torch.equal(grp2, grp)
     n["attn"] += 1
     # ---- causal GQA prefill attention behind a cached prefix (head_dim 128: the DMA path; 64: the register path)
     D = (128, 128, 64)[ri(0, 2)]
