@@ -145,6 +145,11 @@ int o3v_linear_decode_fp8(const void* X, const void* norm_w, float eps, const vo
  * K % 64 == 0, N % 16 == 0 (SWIGLU: N % 32 == 0). */
 int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res, void* out,
                                int M, int N, int K, int ldx, int ldo, int ldr, int epilogue, o3v_stream_t stream);
+/* q/k/v on fp8 rows for 4..32 rows of already normalised x: bias, M-RoPE and the cache append in the epilogue (the arguments of
+ * o3v_gemv_norm_qkv_rope without the fused norm; W8p fragment-major as above). */
+int o3v_qkv_rope_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, int M, int K, int ldx, const void* cosT,
+                          const void* sinT, void* qout, void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax,
+                          int cs_stride_row, int cs_off, o3v_stream_t stream);
 int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,
                                const void* bias, int M, int K, int ldx, const void* cosT, const void* sinT, void* qout,
                                void* kcache, void* vcache, int slot, int Hq, int Hkv, int D, int Tmax, int cs_stride_row,

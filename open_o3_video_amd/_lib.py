@@ -113,6 +113,7 @@ SIGNATURES = {
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_qkv_rope_fp8_rows": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode_fp8_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_norm_qkv_rope_fp8": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

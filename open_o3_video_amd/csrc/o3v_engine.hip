@@ -423,7 +423,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
     const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
     // fp8 rows at 4..32 rows (BASELINE config #5: N = 16 chains on fp8 weights): norms run apart, the linears stream the
-    // fragment-major fp8 images (q/k/v only where the rotation is not fused into the linear, i.e. Qwen3-VL)
+    // fragment-major fp8 images
     const bool fp8b = B >= 4 && d->layer[0].gu_w8p && d->layer[0].down_w8p && d->layer[0].o_w8p;
     const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
     bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
@@ -448,6 +448,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                                       O3V_EPI_NONE, s));
             TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, st->cosT, st->sinT, w.q, kc, vc, slot0 + step, B, 1, Hq,
                                         Hkv, D, st->Tmax, st->Tnew, step, s));
+        } else if (fp8b && lw.qkv_w8p) {
+            TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+            TRY(o3v_qkv_rope_fp8_rows(w.h, lw.qkv_w8p, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc, slot0 + step, Hq, Hkv, D,
+                                      st->Tmax, st->Tnew, step, s));
         } else if (fp8) {
             TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
                                            kc, vc, slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));

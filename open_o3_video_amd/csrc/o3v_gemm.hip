@@ -665,8 +665,8 @@ template <int EPI, int KS, int CB>
 __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __restrict__ X, const uint8_t* __restrict__ W8p,
                                                             const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
                                                             const bf16_t* __restrict__ res, bf16_t* __restrict__ out, int M, int N,
-                                                            int K, int ldx, int ldo, int ldr) {
-    constexpr int RB = (EPI == EPI_SWIGLU) ? 2 : 1;
+                                                            int K, int ldx, int ldo, int ldr, RopeArgs ra) {
+    constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
     constexpr int RG = 4 / KS;
     constexpr int U = RB == 1 ? 4 : 2;  // double steps per trip: 4 KiB of weights in flight per buffer and wave
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [KS > 1: 4 x RB x CB x 64 x 4 f32]
@@ -678,6 +678,11 @@ __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __rest
     if (EPI == EPI_SWIGLU) {
         rb0[0] = grp * 32;
         rb0[RB - 1] = grp * 32 + 16;
+    } else if (EPI == EPI_QKVROPE) {  // the rotary pair blocks j and j + D/2 of one head (as gemv_mfma_kernel)
+        const int bph = ra.D / 32;
+        const int head = grp / bph, jb = grp % bph;
+        rb0[0] = head * ra.D + jb * 16;
+        rb0[RB - 1] = rb0[0] + ra.D / 2;
     } else {
         rb0[0] = grp * 16;
     }
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __rest
     int t_end = t_begin + per;
     t_end = t_end < nt ? t_end : nt;
 
-    float e_scale[RB][4], e_bias[RB][4], e_res[CB][4];
+    float e_scale[RB][4], e_bias[RB][4], e_res[CB][4], e_cos[CB][4], e_sin[CB][4];
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -711,6 +716,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __rest
             int n = rb0[0] + fg * 4 + r;
             n = n < N ? n : N - 1;
             e_res[cb][r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
+            if (EPI == EPI_QKVROPE) {
+                const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + (rb0[0] < N ? rb0[0] : 0) % ra.D + fg * 4 + r;
+                e_cos[cb][r] = bf2f(ra.cosT[cs]);
+                e_sin[cb][r] = bf2f(ra.sinT[cs]);
+            } else {
+                e_cos[cb][r] = e_sin[cb][r] = 0.f;
+            }
         }
     }
     f32x4 acc[RB][CB];
@@ -801,6 +813,28 @@ __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __rest
                 const float g = rbf(acc[0][cb][r] * e_scale[0][r] + e_bias[0][r]);
                 const float u = rbf(acc[RB - 1][cb][r] * e_scale[RB - 1][r] + e_bias[RB - 1][r]);
                 out[(size_t)m * ldo + no] = f2bf(rbf(silu_f(g)) * u);
+            }
+        } else if (EPI == EPI_QKVROPE) {  // bias, M-RoPE, q out / K,V appended to the cache (TF:557-599, :652-664), as gemv_mfma_kernel
+            const int half = ra.D >> 1, head = rb0[0] / ra.D, j0 = rb0[0] % ra.D + fg * 4;
+            if (rb0[0] >= N) return;  // block-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r;
+                const float v0 = rbf(acc[0][cb][r] * e_scale[0][r] + e_bias[0][r]);
+                const float v1 = rbf(acc[RB - 1][cb][r] * e_scale[RB - 1][r] + e_bias[RB - 1][r]);
+                if (head >= ra.Hq + ra.Hkv) {
+                    bf16_t* dst = ra.vc + (((size_t)m * ra.Hkv + (head - ra.Hq - ra.Hkv)) * ra.Tmax + ra.slot) * ra.D;
+                    dst[j] = f2bf(v0);
+                    dst[j + half] = f2bf(v1);
+                    continue;
+                }
+                const float c = e_cos[cb][r], sn = e_sin[cb][r];
+                const float o0 = __fadd_rn(rbf(__fmul_rn(v0, c)), rbf(__fmul_rn(-v1, sn)));
+                const float o1 = __fadd_rn(rbf(__fmul_rn(v1, c)), rbf(__fmul_rn(v0, sn)));
+                bf16_t* dst = head < ra.Hq ? ra.qout + ((size_t)m * ra.Hq + head) * ra.D
+                                           : ra.kc + (((size_t)m * ra.Hkv + (head - ra.Hq)) * ra.Tmax + ra.slot) * ra.D;
+                dst[j] = f2bf(o0);
+                dst[j + half] = f2bf(o1);
             }
         } else {
 #pragma unroll
@@ -1247,14 +1281,15 @@ extern "C" int o3v_linear_decode_fp8(const void* X, const void* norm_w, float ep
 }
 
 // fp8 rows at 4..32 rows of x (already normalised): the matrix-core kernel above on the fragment-major fp8 image W8p.
-// epilogue NONE / RESIDUAL / SWIGLU (W8p then packs the interleaved gate/up matrix), K % 64 == 0, N % 16 == 0.
-extern "C" int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res,
-                                          void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue, hipStream_t stream) {
-    if (!X || !W8p || !scale || !out || M < 4 || M > 32 || N <= 0 || K <= 0) return O3V_ERR_ARG;
-    if ((K & 63) || (N & 15) || (ldx & 7) || (epilogue == EPI_SWIGLU && (N & 31))) return O3V_ERR_SHAPE;
+// epilogue NONE / RESIDUAL / SWIGLU (W8p then packs the interleaved gate/up matrix) / QKVROPE, K % 64 == 0, N % 16 == 0.
+static int launch_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res, void* out, int M, int N,
+                           int K, int ldx, int ldo, int ldr, int epilogue, const RopeArgs& ra, hipStream_t stream) {
+    if (!X || !W8p || !scale || M < 4 || M > 32 || N <= 0 || K <= 0) return O3V_ERR_ARG;
+    if ((K & 63) || (N & 15) || (ldx & 7) || ((epilogue == EPI_SWIGLU || epilogue == EPI_QKVROPE) && (N & 31))) return O3V_ERR_SHAPE;
+    if (epilogue == EPI_QKVROPE && (ra.D % 32)) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
-    const int RB = epilogue == EPI_SWIGLU ? 2 : 1;
-    const int groups = epilogue == EPI_SWIGLU ? N / 32 : N / 16;
+    const int RB = (epilogue == EPI_SWIGLU || epilogue == EPI_QKVROPE) ? 2 : 1;
+    const int groups = RB == 2 ? N / 32 : N / 16;
     const int ks = groups >= 2048 ? 1 : 4;  // as the bf16 kernel: >= 8 waves per CU
     const int cbn = M > 16 ? 2 : 1;
 #define O3V_F8K(E, KK, CC)                                                                                                       \
@@ -1263,7 +1298,7 @@ extern "C" int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const 
         const dim3 grid((groups + RG_ - 1) / RG_), block(256);                                                                   \
         const size_t sh = KK > 1 ? (size_t)4 * RB * CC * 64 * 16 : 0;                                                            \
         O3V_KLAUNCH((gemv_mfma_fp8_kernel<E, KK, CC>), grid, block, sh, stream, (const bf16_t*)X, (const uint8_t*)W8p, scale,    \
-                    (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, ldx, ldo, ldr);                              \
+                    (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)out, M, N, K, ldx, ldo, ldr, ra);                          \
     } while (0)
 #define O3V_F8E(E)                       \
     do {                                 \
@@ -1283,12 +1318,30 @@ extern "C" int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const 
         case EPI_NONE: O3V_F8E(EPI_NONE); break;
         case EPI_RESIDUAL: O3V_F8E(EPI_RESIDUAL); break;
         case EPI_SWIGLU: O3V_F8E(EPI_SWIGLU); break;
+        case EPI_QKVROPE: O3V_F8E(EPI_QKVROPE); break;
         default: return O3V_ERR_ARG;
     }
 #undef O3V_F8E
 #undef O3V_F8K
     O3V_CHECK_LAUNCH();
     return O3V_OK;
+}
+
+extern "C" int o3v_linear_decode_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, const void* res,
+                                          void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue, hipStream_t stream) {
+    if (!out || epilogue == EPI_QKVROPE) return O3V_ERR_ARG;
+    return launch_fp8_rows(X, W8p, scale, bias, res, out, M, N, K, ldx, ldo, ldr, epilogue, RopeArgs{}, stream);
+}
+
+// q/k/v on fp8 rows for 4..32 rows of already normalised x, with bias, M-RoPE and the cache append in the epilogue (the
+// arguments of o3v_gemv_norm_qkv_rope without the fused norm)
+extern "C" int o3v_qkv_rope_fp8_rows(const void* X, const void* W8p, const float* scale, const void* bias, int M, int K, int ldx,
+                                     const void* cosT, const void* sinT, void* qout, void* kcache, void* vcache, int slot, int Hq,
+                                     int Hkv, int D, int Tmax, int cs_stride_row, int cs_off, hipStream_t stream) {
+    if (!cosT || !sinT || !qout || !kcache || !vcache || slot < 0 || slot >= Tmax || Hq <= 0 || Hkv <= 0 || (D & 1)) return O3V_ERR_ARG;
+    const RopeArgs ra{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)qout, (bf16_t*)kcache, (bf16_t*)vcache,
+                      slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
+    return launch_fp8_rows(X, W8p, scale, bias, nullptr, nullptr, M, (Hq + 2 * Hkv) * D, K, ldx, 0, 0, EPI_QKVROPE, ra, stream);
 }
 
 extern "C" int o3v_gemv_norm_qkv_rope_fp8(const void* X, const void* norm_w, float eps, const void* W8, const float* scale,

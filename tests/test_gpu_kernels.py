@@ -493,6 +493,44 @@ def test_linear_decode_fp8_rows(dev, M, N, K, epi_name):
     assert _lib.load().o3v_linear_decode_fp8_rows(P(x), P(q8p), P(sc), None, None, P(out), 3, N, K, K, No, N, ops.EPI_NONE, st) == _lib.ERR_ARG
 
 
+@pytest.mark.parametrize("M,Hq,Hkv,D,K", [(4, 28, 4, 128, 3584), (16, 28, 4, 128, 3584), (32, 16, 2, 128, 2048), (9, 4, 2, 32, 128), (24, 8, 2, 64, 256)])
+def test_qkv_rope_fp8_rows(dev, M, Hq, Hkv, D, K):
+    """q/k/v on fp8 rows at 4..32 rows with bias, M-RoPE and the cache append in the epilogue == the bf16 matrix-core kernel on the
+    dequantised weights (exact in bf16) up to the summation order."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import dequantize_rows_fp8, pack_mfma_fragments, pack_mfma_fragments_fp8, quantize_rows_fp8
+    g = torch.Generator().manual_seed(M + Hq + K)
+    N, Tmax, Tnew, step, slot = (Hq + 2 * Hkv) * D, 40, 6, 4, 33
+    x = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    q8, sc = quantize_rows_fp8(w)
+    wq = dequantize_rows_fp8(q8, sc).to(BF)
+    q8p = pack_mfma_fragments_fp8(q8)
+    bias = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    ang = torch.rand(M, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for fp8 in (False, True):
+        q = torch.zeros(M, Hq, D, dtype=BF, device=dev)
+        kc = torch.zeros(M, Hkv, Tmax, D, dtype=BF, device=dev)
+        vc = torch.zeros_like(kc)
+        if fp8:
+            _lib.call("o3v_qkv_rope_fp8_rows", P(x), P(q8p), P(sc), P(bias), M, K, K, P(cos), P(sin), P(q), P(kc), P(vc), slot, Hq, Hkv, D,
+                      Tmax, Tnew, step, st)
+        else:
+            wqp = pack_mfma_fragments(wq) if K % 32 == 0 else None
+            _lib.call("o3v_gemv_norm_qkv_rope", P(x), None, 0.0, P(wq), P(wqp), P(bias), M, K, K, P(cos), P(sin), P(q), P(kc), P(vc), slot,
+                      Hq, Hkv, D, Tmax, Tnew, step, st)
+        outs.append((q, kc, vc))
+    for t1, t2 in zip(*outs):
+        close_bf16(t2, t1.float(), ulps=1, atol=2e-3, frac=0.998)
+    assert (outs[1][1][:, :, :slot] == 0).all() and (outs[1][1][:, :, slot + 1:] == 0).all()
+
+
 def test_gemm_rejects_bad_shapes(dev):
     import kernel_ops as ops
     from open_o3_video_amd import _lib

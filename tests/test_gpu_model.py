@@ -461,3 +461,35 @@ def test_fp8_decode_weights_engine(need_gpu):
     d = (a.margins[0, :k] - b.margins[0, :k]).abs().max().item() if k else 0.0
     print(f"   margins bf16-rows vs fp8-rows over {k} common steps: max |diff| {d:.4f}")
     assert d < LOGIT_ATOL
+
+
+def test_fp8_rows_batched_decode_engine(need_gpu):
+    """fp8 rows at 4..32 decode rows through the engine on a Qwen2.5-VL fixture (fragment-major fp8 images on the matrix cores for
+    q/k/v with the fused rotation, o_proj, gate/up, down_proj and the lm_head): with fp8-representable weights the greedy rows of a
+    G-way group follow the bf16-row engine wherever its margin is safe (same weight values, other summation order)."""
+    from open_o3_video_amd.config import O3VConfig
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, dequantize_rows_fp8, getter_from_dict, quantize_rows_fp8
+    cfg = fm.medium_config()
+    W = fm.make_weights(cfg, 6)
+    for k in list(W):
+        if k.startswith("model.language_model.layers.") and k.endswith("_proj.weight") or k == "lm_head.weight":
+            q8, sc = quantize_rows_fp8(W[k].to(torch.bfloat16))
+            W[k] = dequantize_rows_fp8(q8, sc)
+    frames = fm.make_frames(2, 112, 140, seed=3)
+    c = O3VConfig.from_dict(cfg)
+    e1 = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda"))
+    e2 = O3VEngine(c, DeviceWeights(c, getter_from_dict(W), "cuda", fp8_decode=True))
+    assert e2.w.llm.layer[0].qkv_w8p and e2.w.llm.layer[0].down_w8p and e2.w.llm.lm_head8p
+    px, grid = e1.pixels_from_frames(frames)
+    ids = np.asarray([fm.make_prompt(cfg, [tuple(g) for g in grid.tolist()], seed=3)])
+    n_new = 10
+    for G in (4, 8, 19):
+        a = e1.generate(ids, None, frames=frames, max_new_tokens=n_new, num_return_sequences=G, pad_token_id=cfg["pad_token_id"])
+        b = e2.generate(ids, None, frames=frames, max_new_tokens=n_new, num_return_sequences=G, pad_token_id=cfg["pad_token_id"])
+        ra, rb, m = a.sequences[G - 1, -n_new:].tolist(), b.sequences[G - 1, -n_new:].tolist(), a.margins[G - 1].tolist()
+        k = 0
+        while k < n_new and ra[k] == rb[k]:
+            k += 1
+        print(f"fp8 rows, {G} decode rows: follow the bf16 rows for {k}/{n_new} tokens")
+        assert k == n_new or m[k] < 2 * LOGIT_ATOL, (G, k, m[k])
