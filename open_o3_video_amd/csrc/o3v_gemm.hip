@@ -668,7 +668,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_fp8_kernel(const bf16_t* __rest
                                                             int K, int ldx, int ldo, int ldr, RopeArgs ra) {
     constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
     constexpr int RG = 4 / KS;
-    constexpr int U = RB == 1 ? 4 : 2;  // double steps per trip: 4 KiB of weights in flight per buffer and wave
+#ifndef O3V_F8_U1  // (overridable for A/B builds: tools/probes/rollout_probe.py)
+#define O3V_F8_U1 8
+#define O3V_F8_U2 2
+#endif
+    // double steps per trip: 8 KiB of weights in flight per buffer and wave for the single row block, 4 KiB for the paired ones
+    // (7B rollouts on fp8 rows, G = 8 / 16: (4,2) 2.877 / 3.344, (8,4) 2.888 / 3.363, (2,1) 3.007 / 3.352, (8,2) 2.826 / 3.310 ms/step)
+    constexpr int U = RB == 1 ? O3V_F8_U1 : O3V_F8_U2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [KS > 1: 4 x RB x CB x 64 x 4 f32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
