@@ -284,3 +284,33 @@ def test_ctx_handle_owns_descriptor_copies():
     lib.o3v_ctx_destroy(None)
     bad = _lib.LlmDesc(layers=2)              # layers without a layer array
     assert not lib.o3v_ctx_create(C.byref(bad), None, None)
+
+
+def test_fp8_quantiser_and_fragment_packing():
+    """weights.quantize_rows_fp8 (power-of-two row scales, exact bf16 dequantisation) and the two fragment-major packings the
+    matrix-core decode kernels read (bf16: [N/16][K/32][64][8], fp8: [N/16][K/64][64][16]): index maps as documented."""
+    from open_o3_video_amd.weights import (FP8_MAX, dequantize_rows_fp8, pack_mfma_fragments, pack_mfma_fragments_fp8,
+                                           quantize_rows_fp8)
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(32, 128, generator=g) * torch.logspace(-3, 1, 32)[:, None]).to(torch.bfloat16)
+    w[5] = 0
+    q8, sc = quantize_rows_fp8(w)
+    assert q8.dtype == torch.uint8 and sc.dtype == torch.float32 and sc[5] == 1.0
+    assert torch.equal(torch.exp2(torch.round(torch.log2(sc))), sc)                      # powers of two
+    deq = dequantize_rows_fp8(q8, sc)
+    assert torch.equal(deq, deq.to(torch.bfloat16).float())                              # exact in bf16
+    assert (deq.abs().amax(1) <= sc * FP8_MAX).all()
+    rel = ((deq - w.float()).abs() / w.float().abs().clamp(min=1e-9))[w.float().abs() > sc[:, None] * 2.0 ** -6]
+    assert rel.max() <= 2.0 ** -4 + 1e-6                                                 # 3 mantissa bits: half an ulp of 2^-3
+    q2, s2 = quantize_rows_fp8(deq.to(torch.bfloat16))
+    assert torch.equal(dequantize_rows_fp8(q2, s2), deq)                                 # value-idempotent
+    # bf16 fragments: lane l of (row block nb, k-step ks) holds W[nb*16 + (l & 15)][ks*32 + (l >> 4)*8 : +8]
+    wi = torch.arange(32 * 128, dtype=torch.int32).view(32, 128)
+    p = pack_mfma_fragments(wi).view(2, 4, 64, 8)
+    for nb, ks, l in ((0, 0, 0), (1, 3, 37), (0, 2, 63)):
+        assert torch.equal(p[nb, ks, l], wi[nb * 16 + (l & 15), ks * 32 + (l >> 4) * 8: ks * 32 + (l >> 4) * 8 + 8])
+    # fp8 fragments: lane l of (row block nb, double step t) holds W[nb*16 + (l & 15)][t*64 + (l >> 4)*16 : +16]
+    bi = (torch.arange(32 * 128) % 251).to(torch.uint8).view(32, 128)
+    p8 = pack_mfma_fragments_fp8(bi).view(2, 2, 64, 16)
+    for nb, t, l in ((0, 0, 0), (1, 1, 37), (0, 1, 63)):
+        assert torch.equal(p8[nb, t, l], bi[nb * 16 + (l & 15), t * 64 + (l >> 4) * 16: t * 64 + (l >> 4) * 16 + 16])
