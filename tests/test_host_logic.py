@@ -139,6 +139,28 @@ def test_c_abi_argument_errors_without_gpu():
     assert lib.o3v_attn_tiles(p, p, p, p, p, 0, 64, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.OK
     assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 64, 4, 1, 48, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_SHAPE
     assert lib.o3v_attn_tiles(p, p, p, p, p, 1, 96, 4, 1, 80, 240, 240, 80, 0, 240, 80, 0, 80, 0.1, None) == _lib.ERR_ARG
+    # this round's entries: shared prompt entries, 17..32 rows, fp8 rows, Qwen3-VL ops, the one-launch block
+    assert lib.o3v_attn_tiles_prefix(p, p, p, p, None, 0, 0, 5, 1, p, p, 1, 64, 4, 1, 128, 512, 128, 0, 0, 128, 0, 0, 512, 0.1, None) == _lib.ERR_ARG
+    assert lib.o3v_attn_tiles_prefix(p, p, p, p, p, 0, 0, 0, 1, p, p, 1, 64, 4, 1, 128, 512, 128, 0, 0, 128, 0, 0, 512, 0.1, None) == _lib.ERR_ARG
+    f32p = ctypes.cast(buf, ctypes.POINTER(ctypes.c_float))
+    assert lib.o3v_attn_decode_group_prefix(p, p, p, p, p, 10, 3, p, f32p, f32p, None, 8, 4, 8, 2, 128, 10, 12, 8, 2, 0.1, None) == _lib.ERR_ARG  # 4 rows per group do not divide 3 rows per prompt
+    assert lib.o3v_attn_decode_group_prefix(p, p, p, p, p, 10, 4, p, f32p, f32p, None, 8, 4, 8, 2, 64, 10, 12, 8, 2, 0.1, None) == _lib.ERR_SHAPE  # head_dim 64
+    assert lib.o3v_linear_decode(p, p, 1e-6, p, p, None, None, p, 17, 64, 64, 64, 64, 0, _lib.EPI_NONE, None) == _lib.ERR_SHAPE  # fused norm above 16 rows
+    assert lib.o3v_linear_decode(p, None, 0.0, p, None, None, None, p, 33, 64, 64, 64, 64, 0, _lib.EPI_NONE, None) == _lib.ERR_SHAPE
+    assert lib.o3v_linear_decode_fp8_rows(p, p, f32p, None, None, p, 3, 64, 64, 64, 64, 0, _lib.EPI_NONE, None) == _lib.ERR_ARG
+    assert lib.o3v_linear_decode_fp8_rows(p, p, f32p, None, None, p, 8, 64, 96, 96, 64, 0, _lib.EPI_NONE, None) == _lib.ERR_SHAPE  # K % 64
+    assert lib.o3v_linear_decode_fp8_rows(p, p, f32p, None, None, p, 8, 64, 64, 64, 64, 0, _lib.EPI_RESIDUAL, None) == _lib.ERR_ARG  # no residual
+    assert lib.o3v_layernorm(p, p, None, p, 1, 64, 64, 64, 1e-6, None) == _lib.ERR_ARG
+    assert lib.o3v_qkv_norm_rope_cache(p, p, p, 1e-6, p, p, p, p, p, 0, 1, 1, 4, 2, 96, 8, 1, 0, None) == _lib.ERR_SHAPE  # 6 lanes per head
+    assert lib.o3v_add_rows(p, p, p, p, 0, 64, None) == _lib.OK
+    assert lib.o3v_patchify_ps(p, 1, p, 1, 48, 64, 1536, 16, ctypes.cast(buf, ctypes.POINTER(ctypes.c_float)),
+                               ctypes.cast(buf, ctypes.POINTER(ctypes.c_float)), None) == _lib.ERR_ARG                # 48 is not a multiple of 32
+    assert lib.o3v_decode_attn_block_qknorm(p, p, 1e-6, p, None, p, None, None, p, p, p, p, p, p, p, p, f32p, f32p, None, 64, 2, 1, 128, 0, 4, 1,
+                                            0, 1, 0.1, ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint32)), 1, None) == _lib.ERR_ARG  # no q_norm
+    assert lib.o3v_vit3_forward(None, p, 4, p, f32p, f32p, p, 1, p, 64, p, None, None) == _lib.ERR_ARG
+    opts = _lib.PrefillOpts(kprefix=ctypes.addressof(buf), vprefix=0, prefix_len=4, prefix_cap=4, rows_per_prefix=1)
+    d = _lib.LlmDesc(hidden=64, layers=0, heads=2, kv_heads=1, head_dim=32, inter=64, vocab=8, rms_eps=1e-6)
+    assert lib.o3v_llm_prefill_ex(ctypes.byref(d), p, p, p, p, 1, 128, p, p, 1, 4, 4, 8, ctypes.byref(opts), p, 64, None) == _lib.ERR_ARG  # K without V
 
 
 def test_engine_refuses_to_run_without_gpu():
