@@ -942,6 +942,9 @@ int launch_gemv_m(const GemvArgs& a) {
 #define O3V_T2(NN, UV) if (g_tune_R == 100 + NN && g_tune_KS == UV) return launch_gemv<M, 2, 1, NORM, NN, WB, UV>(a)
         O3V_T2(4, 2); O3V_T2(4, 4); O3V_T2(4, 8); O3V_T2(8, 4); O3V_T2(8, 2); O3V_T2(16, 4); O3V_T2(2, 4); O3V_T2(8, 8);
         O3V_T2(1, 4); O3V_T2(1, 2); O3V_T2(2, 2); O3V_T2(3, 4); O3V_T2(2, 6); O3V_T2(1, 6);
+#define O3V_T3(NN, UV) if (g_tune_R == 300 + NN && g_tune_KS == UV) return launch_gemv<M, 2, 2, NORM, NN, WB, UV>(a)
+        O3V_T3(14, 4); O3V_T3(14, 2); O3V_T3(14, 6); O3V_T3(8, 4); O3V_T3(6, 4); O3V_T3(10, 4); O3V_T3(16, 4); O3V_T3(12, 4); O3V_T3(4, 4);
+#undef O3V_T3
 #define O3V_T4(NN, UV) if (g_tune_R == 200 + NN && g_tune_KS == UV) return launch_gemv<M, 4, 1, NORM, NN, WB, UV>(a)
         O3V_T4(2, 2); O3V_T4(3, 2); O3V_T4(2, 4); O3V_T4(4, 4); O3V_T4(8, 2); O3V_T4(2, 1);
 #undef O3V_T4

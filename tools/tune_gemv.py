@@ -43,6 +43,9 @@ def main():
     if "--wg" in sys.argv:        # R = 2, KS = 1 with other workgroup sizes and trip depths: variant (100 + NW, k-steps per trip)
         variants = [(0, 0), (104, 4), (102, 4), (102, 2), (102, 6), (101, 4), (101, 2), (101, 6), (103, 4)]
         shapes = {k: shapes[k] for k in ("gate_up", "down", "lm_head")}
+    if "--down" in sys.argv:      # R = 2, KS = 2 (long rows split over wave pairs) with other workgroup sizes / trip depths
+        variants = [(0, 0), (314, 4), (314, 2), (314, 6), (308, 4), (306, 4), (310, 4), (316, 4), (312, 4), (304, 4)]
+        shapes = {k: shapes[k] for k in ("down",)}
     if "--wg4" in sys.argv:       # R = 4 (two pairs per wave; the fp8 choice) with other workgroup sizes / trip depths
         variants = [(0, 0), (4, 1), (202, 2), (203, 2), (202, 4), (204, 4), (208, 2), (202, 1), (102, 4), (103, 4)]
         shapes = {k: shapes[k] for k in ("gate_up", "down", "lm_head")}
