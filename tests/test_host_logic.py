@@ -216,6 +216,14 @@ def test_qwen3vl_config_parsing():
                              "mrope_interleaved": True}
     m2 = O3VConfig.from_dict(d)
     assert m2.text.mrope_section == [24, 20, 20] and m2.text.rope_theta == 5000000.0 and m2.text.mrope_interleaved
+    # the hub's config.json layout: rope settings under text_config.rope_scaling, eos / bos inside text_config
+    d = qwen3vl_8b_dict()
+    tc = d["text_config"]
+    tc["rope_scaling"] = {"mrope_interleaved": True, "mrope_section": tc.pop("mrope_section"), "rope_type": "default"}
+    tc["eos_token_id"], tc["bos_token_id"] = d.pop("eos_token_id"), 151643
+    d.pop("pad_token_id")
+    h = O3VConfig.from_dict(d)
+    assert h.text.mrope_section == [24, 20, 20] and h.text.mrope_interleaved and h.eos_token_id == 151645 and h.pad_token_id == 151643
     q25 = O3VConfig.from_dict(qwen25vl_7b_dict())
     assert q25.arch == "qwen2_5_vl" and not q25.text.qk_norm and q25.text.attention_bias and not q25.text.mrope_interleaved
     bad = qwen3vl_8b_dict()
