@@ -86,8 +86,10 @@ class LLM:
                 import json
                 with open(pp) as f:
                     pc = json.load(f)
-                min_pixels = pc.get("min_pixels", min_pixels)
-                max_pixels = pc.get("max_pixels", max_pixels)
+                # either the flat keys or transformers 5.x's size = {shortest_edge: min pixels, longest_edge: max pixels}
+                size = pc.get("size") or {}
+                min_pixels = pc.get("min_pixels") or size.get("shortest_edge") or min_pixels
+                max_pixels = pc.get("max_pixels") or size.get("longest_edge") or max_pixels
         if tokenizer is None:
             raise ValueError("a tokenizer is required (encode / decode / convert_tokens_to_ids)")
         self.generation_eos_ids = []

@@ -98,8 +98,10 @@ def test_from_pretrained_local_dir_with_hub_names(need_gpu, tmp_path, golden_dir
         Qwen2_5_VLForConditionalGeneration.from_pretrained("Qwen/Qwen2.5-VL-7B-Instruct")  # never downloads
     # vLLM's quantization="fp8": fp8 decode rows are built on load from the bf16 checkpoint
     from open_o3_video_amd.vllm_api import LLM
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"size": {"shortest_edge": 3136, "longest_edge": 200704}}))
     llm = LLM(model=str(tmp_path), tokenizer=StubTokenizer(cfg), quantization="fp8")
     assert llm.engine.w.fp8_decode and llm.engine.w.llm.lm_head8
+    assert (llm.min_pixels, llm.max_pixels) == (3136, 200704)       # transformers 5.x layout of the processor's pixel budget
     with pytest.raises(ValueError):
         LLM(model=str(tmp_path), tokenizer=StubTokenizer(cfg), quantization="awq")
 
