@@ -260,7 +260,8 @@ def rollout_leg(cfg, eng, ids, pixel_values, grid, dist, dev, G=8, T=768, steps=
     return {"G": G, "max_completion_length": T, "steps": steps, "prompts_per_step": world, "tokens_per_s": round(n_all / dt, 1),
             "ms_per_step": round(dt / steps * 1e3, 1), "record_columns": int(res.rewards_per_func.shape[1]) + 4,
             "collective": "one all_gather_into_tensor of the packed [G, n_rewards+4] f32 record per step"
-                          + ("" if dist else " (skipped: one rank)")}
+                          + ("" if dist else " (skipped: no process group)"),
+            "backend": dist.get_backend() if dist else None}
 
 
 def launch_check():
@@ -307,6 +308,12 @@ def main():
         launch_check()
         return
 
+    # stdout carries exactly ONE line, the result: libraries that write to file descriptor 1 (RCCL prints a version banner there
+    # when a communicator is created) are sent to stderr for the whole run; the result line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
@@ -330,6 +337,17 @@ def main():
         dist = dist_
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"world size {dist.get_world_size()} != --gpus {args.gpus}")
+    elif backend == "nccl" and os.environ.get("O3V_BENCH_SOLO_GROUP", "1") != "0":
+        # N = 1: a one-rank RCCL group, so that the rollout leg's all_gather / barriers run through the library the N = 8 run uses
+        try:
+            import torch.distributed as dist_
+            from open_o3_video_amd.launch import free_port
+            dist_.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                     device_id=torch.device("cuda", local_rank))
+            dist = dist_
+        except Exception as e:   # the headline does not depend on it
+            print(f"[bench] one-rank nccl group not available ({type(e).__name__}: {e}); the rollout leg skips its collective", file=sys.stderr)
+            dist = None
 
     from open_o3_video_amd.config import O3VConfig, qwen25vl_3b_dict, qwen25vl_7b_dict
     from open_o3_video_amd.engine import O3VEngine
@@ -483,7 +501,9 @@ def main():
         if not args.no_cpu_baseline and n_gpus == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg_dict, args.frames, Hres, Wres, S, args.new_tokens)
             rec["cpu_baseline"]["config1_full"] = cpu_baseline_config1()
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(rec) + "\n").encode())
+    os.close(result_fd)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
