@@ -383,7 +383,8 @@ typedef struct {
 int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
                        int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax,
                        const o3v_prefill_opts* opts, void* workspace, size_t ws_bytes, o3v_stream_t stream);
-/* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387 */
+/* final norm + lm_head on `rows` rows of x (row stride ldx): logits bf16 [rows, vocab]  TF:867, :1386-1387.  Always the bf16
+ * head (prefill, forward_logits, the log-prob pass); the fp8 head is used inside o3v_llm_decode only. */
 int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                  o3v_stream_t stream);
 

@@ -360,11 +360,21 @@ extern "C" int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* co
     return O3V_OK;
 }
 
+namespace {
+int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s);
+}
+// bf16 weights always: the head of the prefill, of forward_logits and of the log-prob pass (R:grpo_trainer.py:371-384) -- the fp8
+// rows are DECODE rows (o3v_llm_decode streams them), a log-prob must not depend on how many rows its chunk happens to hold
 extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                             o3v_stream_t s) {
+    return llm_head(d, x, ldx, rows, normed, logits, false, s);
+}
+
+namespace {
+int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
-    if (rows >= 4 && rows <= 32 && d->lm_head8p) {  // batched decode on fp8 rows: norm apart, fp8 fragments widened in registers
+    if (fp8_rows && rows >= 4 && rows <= 32 && d->lm_head8p) {  // batched decode on fp8 rows: norm apart, fp8 fragments widened in registers
         TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
         return o3v_linear_decode_fp8_rows(normed, d->lm_head8p, d->lm_head_s, nullptr, nullptr, logits, rows, d->vocab, H, H, d->vocab, 0,
                                           O3V_EPI_NONE, s);
@@ -374,7 +384,7 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
         return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
                                  d->vocab, 0, O3V_EPI_NONE, s);
     }
-    if (rows <= 3 && d->lm_head8)  // fp8 head (decode with fp8 weights): half the 1.09 GB
+    if (fp8_rows && rows <= 3 && d->lm_head8)  // fp8 head (decode with fp8 weights): half the 1.09 GB
         return o3v_linear_decode_fp8(x, d->final_norm, d->rms_eps, d->lm_head8, d->lm_head_s, nullptr, nullptr, logits, rows,
                                      d->vocab, H, ldx, d->vocab, 0, O3V_EPI_NONE, s);
     if (rows <= 8)  // decode / last-token head: RMSNorm fused into the weight-streaming GEMV
@@ -390,6 +400,7 @@ extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int r
     }
     return O3V_OK;
 }
+}  // namespace
 
 extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st, int step0, int n_steps,
                               int skip_last_forward, o3v_stream_t s) {
@@ -541,7 +552,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_linear_decode(w.mlp, nullptr, 0.f, lw.down_w, lw.down_wp, nullptr, st->x, st->x, B, H, I, I, H, H,
                                   O3V_EPI_RESIDUAL, s));
         }
-        TRY(o3v_llm_head(d, st->x, H, B, w.normed, st->logits, s));
+        TRY(llm_head(d, st->x, H, B, w.normed, st->logits, true, s));
     }
     return O3V_OK;
 }
