@@ -48,17 +48,32 @@ def load_generation_config(path: str) -> dict:
     return {k: v for k, v in d.items() if k in _GEN_FIELDS and v is not None}
 
 
-def resolve_generation_config(passed, model_gc, kwargs) -> dict:
-    """GenerationMixin._prepare_generation_config (TF:generation/utils.py, 5.15): priority kwargs > the passed
-    generation_config's set fields > model.generation_config (the checkpoint's generation_config.json) > global defaults
-    (top_k 50, repetition_penalty 1.0, ...).  So a trainer config that leaves top_k / eos_token_id / repetition_penalty
-    unset (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:306-313) inherits them from the checkpoint, then from the defaults."""
+_SPECIAL_TOKEN_FIELDS = ("pad_token_id", "eos_token_id", "bos_token_id")
+
+
+def resolve_generation_config(passed, model_gc, kwargs, mode: str = "pinned") -> dict:
+    """GenerationMixin._prepare_generation_config.  Priority: generate() kwargs > the passed generation_config > ... and the
+    rest depends on the library version, hence `mode`:
+
+    "pinned" (default) -- the library the reference installs (transformers @336dc69d, R:setup.sh:4, before 4.50): a PASSED
+        generation_config is used as it is; only the special tokens it leaves unset (eos / pad / bos) fall back to the model's
+        generation config, everything else it does not carry takes GenerationConfig()'s constructor defaults (top_k 50,
+        repetition_penalty 1.0, temperature 1.0, top_p 1.0).  So the trainer's config (R:src/r1-v/src/open_r1/trainer/
+        grpo_trainer.py:306-313) samples with top_k = 50 and no repetition penalty whatever the checkpoint's
+        generation_config.json says.  With NO passed config the model's generation config is the base.  Restated from the
+        published behaviour of that release line; the pinned commit is not installed here: parity unpinned.
+    "tf5" -- transformers >= 5 (5.15 installed here, golden G8b): GenerationConfig() leaves what it was not given at None
+        and every such field is taken from the model's generation config (the checkpoint's generation_config.json) before
+        the global defaults."""
+    if mode not in ("pinned", "tf5"):
+        raise ValueError(f"mode={mode!r}: 'pinned' or 'tf5'")
     out = {}
     for k in _GEN_FIELDS:
         v = kwargs.get(k)
         if v is None and passed is not None:
             v = getattr(passed, k, None)
-        if v is None and model_gc is not None:
+        from_model = mode == "tf5" or passed is None or k in _SPECIAL_TOKEN_FIELDS
+        if v is None and model_gc is not None and from_model:
             v = getattr(model_gc, k, None)
         if v is None:
             v = GLOBAL_GENERATION_DEFAULTS.get(k)
@@ -79,6 +94,9 @@ class Qwen2_5_VLForConditionalGeneration:
         self.generation_config = GenerationConfigLike(pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id)
         self.training = False
         self._seed = 0
+        # how a passed GenerationConfig is completed from the checkpoint's (resolve_generation_config): "pinned" = the library
+        # version the reference installs, "tf5" = transformers >= 5
+        self.generation_config_mode = "pinned"
 
     # ---- construction
     @classmethod
@@ -128,7 +146,7 @@ class Qwen2_5_VLForConditionalGeneration:
                  pixel_values_videos=None, video_grid_thw=None, generation_config=None, **kw):
         if pixel_values is None and pixel_values_videos is not None:
             pixel_values, image_grid_thw = self._video_as_images(pixel_values_videos, video_grid_thw)
-        r = resolve_generation_config(generation_config, self.generation_config, kw)
+        r = resolve_generation_config(generation_config, self.generation_config, kw, self.generation_config_mode)
         G, T, do_sample = int(r["num_return_sequences"]), int(r["max_new_tokens"]), bool(r["do_sample"])
         eos = r["eos_token_id"]
         eos = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])

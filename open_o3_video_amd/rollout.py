@@ -84,7 +84,7 @@ class GroupRollout:
                  eos_token_id: int, pad_token_id: int, ref_model=None, num_generations: int = 4,
                  max_completion_length: int = 768, max_prompt_length: Optional[int] = 16384, beta: float = 0.04,
                  epsilon_low: float = 0.2, epsilon_high: float = 0.2, temperature: float = 1.0, top_p: float = 0.95,
-                 gspo: bool = True, group_parallel: bool = False):
+                 gspo: bool = True, group_parallel: bool = False, top_k: int = 50):
         self.model, self.ref_model = model, ref_model
         self.reward_funcs = list(reward_funcs)
         self.decode = decode
@@ -98,6 +98,7 @@ class GroupRollout:
         self.max_prompt_length = max_prompt_length
         self.beta, self.el, self.eh = beta, epsilon_low, epsilon_high
         self.temperature, self.top_p, self.gspo = temperature, top_p, gspo
+        self.top_k = int(top_k)
 
     @torch.no_grad()
     def step(self, prompt_inputs: dict, example: dict) -> RolloutResult:
@@ -114,11 +115,14 @@ class GroupRollout:
         if sharded and self.G % world:
             raise ValueError(f"num_generations={self.G} is not divisible by the {world} ranks of the group")
         G_local = self.G // world if sharded else self.G
-        # exactly the fields the trainer sets (R:…:306-313): top_k, eos_token_id and repetition_penalty stay unset and are
-        # resolved by the model the way HF does (checkpoint generation_config.json, then top_k 50 / penalty 1.0)
+        # the trainer's GenerationConfig (R:…:306-313) as the library the reference pins completes it (transformers @336dc69d,
+        # R:setup.sh:4): top_k 50 and repetition_penalty 1.0 are that GenerationConfig's own defaults and do NOT come from the
+        # checkpoint's generation_config.json (Qwen2.5-VL ships top_k 1 / penalty 1.05 there: with them all G samples would be
+        # the argmax and every advantage 0).  They are passed explicitly so the rollout does not depend on the façade's
+        # resolution mode; eos / pad / bos are still inherited from the checkpoint, as the pinned library does.
         gc = GenerationConfigLike(max_new_tokens=self.T, do_sample=True, top_p=self.top_p, temperature=self.temperature,
-                                  num_return_sequences=G_local, pad_token_id=self.pad,
-                                  row_id_offset=rank * G_local if sharded else 0)
+                                  top_k=self.top_k, repetition_penalty=1.0, num_return_sequences=G_local,
+                                  pad_token_id=self.pad, row_id_offset=rank * G_local if sharded else 0)
         pc = self.model.generate(input_ids=ids, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
                                  generation_config=gc)
         S = ids.shape[1]

@@ -190,12 +190,67 @@ def test_generation_config_resolution_matches_hf(golden_dir, tmp_path):
         model_gc = GenerationConfigLike(**loaded)
         for suffix, kw in (("", {}), ("+kwargs", {"top_k": 7, "eos_token_id": 3})):
             want = cases["resolved"][name + suffix]
-            got = resolve_generation_config(passed, model_gc, kw)
+            got = resolve_generation_config(passed, model_gc, kw, mode="tf5")
             for k, v in want.items():
                 assert got[k] == v, (name + suffix, k, got[k], v)
     # the unset trainer fields fall back to HF's global defaults when the checkpoint says nothing
-    r = resolve_generation_config(passed, GenerationConfigLike(), {})
+    r = resolve_generation_config(passed, GenerationConfigLike(), {}, mode="tf5")
     assert r["top_k"] == 50 and r["repetition_penalty"] == 1.0 and r["eos_token_id"] is None
+
+
+def test_generation_config_resolution_pinned_library():
+    """mode="pinned" (the default; transformers @336dc69d of R:setup.sh:4): a passed GenerationConfig keeps its own
+    constructor defaults (top_k 50, penalty 1.0) and inherits ONLY eos / pad / bos from the checkpoint -- the trainer's
+    config (R:grpo_trainer.py:306-313) must not pick up Qwen2.5-VL's generation_config.json top_k 1 / penalty 1.05.  With no
+    passed config the checkpoint's config is the base.  Restated behaviour (the pinned commit is not installed): unpinned."""
+    from open_o3_video_amd.hf_api import GenerationConfigLike, resolve_generation_config
+    trainer = GenerationConfigLike(max_new_tokens=768, do_sample=True, top_p=0.95, temperature=1, num_return_sequences=4,
+                                   pad_token_id=151643)
+    ckpt = GenerationConfigLike(do_sample=True, eos_token_id=[151645, 151643], pad_token_id=151643, bos_token_id=151643,
+                                repetition_penalty=1.05, temperature=0.1, top_k=1, top_p=0.001)
+    r = resolve_generation_config(trainer, ckpt, {})
+    assert r["top_k"] == 50 and r["repetition_penalty"] == 1.0 and r["temperature"] == 1 and r["top_p"] == 0.95
+    assert r["eos_token_id"] == [151645, 151643] and r["bos_token_id"] == 151643 and r["num_return_sequences"] == 4
+    r = resolve_generation_config(trainer, ckpt, {"top_k": 7, "eos_token_id": 3})
+    assert r["top_k"] == 7 and r["eos_token_id"] == 3
+    r = resolve_generation_config(None, ckpt, {"max_new_tokens": 5})          # model.generate(**inputs, max_new_tokens=5)
+    assert r["top_k"] == 1 and r["repetition_penalty"] == 1.05 and r["max_new_tokens"] == 5 and r["temperature"] == 0.1
+    with pytest.raises(ValueError):
+        resolve_generation_config(trainer, ckpt, {}, mode="other")
+
+
+def test_group_rollout_sampling_does_not_follow_checkpoint_generation_config():
+    """GroupRollout over a model whose generation_config.json says top_k 1 / penalty 1.05 still samples with the trainer's
+    top_k 50 / penalty 1.0, in either resolution mode; eos is inherited from the checkpoint."""
+    from open_o3_video_amd.hf_api import GenerationConfigLike, Qwen2_5_VLForConditionalGeneration
+    from open_o3_video_amd.rollout import GroupRollout
+    seen = {}
+
+    class Eng:
+        dev = "cpu"
+
+        def generate(self, ids, mask, **kw):
+            seen.update(kw)
+            G, T = kw["num_return_sequences"], 3
+            row = torch.as_tensor(ids, dtype=torch.int64)
+            return types.SimpleNamespace(sequences=torch.cat([row.repeat(G, 1), torch.full((G, T), 7, dtype=torch.int64)], dim=1))
+
+        def completion_logps(self, prompt_ids, completion_ids, mask, **kw):
+            return torch.zeros(completion_ids.shape, dtype=torch.float32)
+
+    import types
+    cfg = O3VConfig.from_dict(fm.tiny_config())
+    for mode in ("pinned", "tf5"):
+        seen.clear()
+        model = Qwen2_5_VLForConditionalGeneration(cfg, Eng())
+        model.generation_config_mode = mode
+        model.generation_config = GenerationConfigLike(do_sample=True, eos_token_id=[510, 509], pad_token_id=511,
+                                                       repetition_penalty=1.05, temperature=0.1, top_k=1, top_p=0.001)
+        ro = GroupRollout(model, [lambda prompts, completions, **kw: [0.0] * len(completions)], lambda c: ["x"] * c.shape[0],
+                          eos_token_id=510, pad_token_id=511, num_generations=4, max_completion_length=3)
+        ro.step({"input_ids": torch.tensor([[11, 12, 13]]), "attention_mask": torch.ones(1, 3, dtype=torch.int64)}, {"prompt": "p"})
+        assert seen["top_k"] == 50 and seen["repetition_penalty"] == 1.0 and seen["temperature"] == 1.0 and seen["top_p"] == 0.95
+        assert seen["do_sample"] is True and seen["eos_token_ids"] == [510, 509] and seen["num_return_sequences"] == 4
 
 
 # ------------------------------------------------------------------------------------------------ Qwen3-VL host logic
