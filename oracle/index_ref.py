@@ -65,15 +65,25 @@ def vision_window_index(grid_thw, merge=2, window_size=112, patch_size=14):
     return np.asarray(window_index, dtype=np.int64), cu[keep]
 
 
-def rope_index(input_ids, mm_token_type_ids, image_grid_thw, attention_mask=None, merge=2):
-    """TF:modeling_qwen2_5_vl.py:944-1058 for images only (the frames-as-images path).
+def rope_index(input_ids, mm_token_type_ids, image_grid_thw, attention_mask=None, merge=2, video_grid_thw=None,
+               second_per_grid_ts=None, tokens_per_second=1, split_video_frames=False):
+    """TF:modeling_qwen2_5_vl.py:944-1058 (+ :892-942 get_vision_position_ids).  mm_token_type_ids: 0 text, 1 image, 2 video.
+    A run of equal types is ONE group and consumes ONE grid row of its modality (TF:1027-1032).  Video groups space the
+    temporal axis by `tokens_per_second * int(second_per_grid_t)` (TF:1046-1047; 1 when second_per_grid_ts is None).
+    split_video_frames: Qwen3-VL (TF:models/qwen3_vl/modeling_qwen3_vl.py:966-969) -- every video grid [t,h,w] becomes t rows
+    [1,h,w] (timestamps separate the frames in the prompt) and no temporal scaling is applied.
 
     Returns position_ids [3,B,S] int64 and rope_deltas [B,1] int64."""
     input_ids = np.asarray(input_ids)
     B, S = input_ids.shape
     pos = np.zeros((3, B, S), dtype=np.int64)
     deltas = []
-    grid_iter = iter([tuple(int(v) for v in g) for g in image_grid_thw])
+    img = [] if image_grid_thw is None else [tuple(int(v) for v in g) for g in np.asarray(image_grid_thw).reshape(-1, 3)]
+    vid = [] if video_grid_thw is None else [tuple(int(v) for v in g) for g in np.asarray(video_grid_thw).reshape(-1, 3)]
+    if split_video_frames:
+        vid = [(1, h, w) for (t, h, w) in vid for _ in range(t)]
+    iters = {1: iter(img), 2: iter(vid)}
+    spg = iter([1] * S if second_per_grid_ts is None else list(second_per_grid_ts))
     for b in range(B):
         types = np.asarray(mm_token_type_ids[b])
         if attention_mask is not None:
@@ -97,20 +107,45 @@ def rope_index(input_ids, mm_token_type_ids, image_grid_thw, attention_mask=None
                 cols.append(np.tile(np.arange(L, dtype=np.int64) + cur, (3, 1)))
                 cur += L
             else:
-                t, h, w = next(grid_iter)
+                t, h, w = next(iters[kind])
+                interval = 1
+                if kind == 2 and not split_video_frames:
+                    interval = int(tokens_per_second) * int(next(spg))       # TF:1047: int() truncates the seconds
                 lh, lw = h // merge, w // merge
-                tt, hh, ww = np.meshgrid(np.arange(t), np.arange(lh) + cur, np.arange(lw) + cur, indexing="ij")
+                tt, hh, ww = np.meshgrid(np.arange(t) * interval, np.arange(lh) + cur, np.arange(lw) + cur, indexing="ij")
                 v = np.stack([tt.reshape(-1) + cur, hh.reshape(-1), ww.reshape(-1)]).astype(np.int64)
                 cols.append(v)
                 cur += max(h, w) // merge
         llm = np.concatenate(cols, axis=1)
-        assert llm.shape[1] == n, "image placeholder count does not match grid"
+        assert llm.shape[1] == n, "placeholder count does not match grid"
         if attention_mask is not None:
             pos[:, b, keep] = llm
         else:
             pos[:, b] = llm
         deltas.append(int(llm.max()) + 1 - n)
     return pos, np.asarray(deltas, dtype=np.int64).reshape(B, 1)
+
+
+def token_types(input_ids, image_token_id, video_token_id):
+    """mm_token_type_ids as the processors build them (TF:models/qwen2_5_vl/processing_qwen2_5_vl.py: 1 at image pads, 2 at
+    video pads)."""
+    ids = np.asarray(input_ids)
+    return (ids == image_token_id).astype(np.int64) + 2 * (ids == video_token_id).astype(np.int64)
+
+
+def patchify_video(frames_f32, patch=14, merge=2, temporal=2):
+    """TF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274 for ONE video: frames_f32 [T,3,H,W] rescaled + normalised.
+    An odd frame count repeats the last frame (:247-250); temporal patch k holds frames 2k and 2k+1; rows are
+    (grid_t, gh/m, gw/m, m, m), columns (channel, t, ph, pw).  -> ([T/2*gh*gw, 3*2*p*p], [[T/2, gh, gw]])."""
+    T, C, H, W = frames_f32.shape
+    if T % temporal:
+        frames_f32 = np.concatenate([frames_f32, np.repeat(frames_f32[-1:], temporal - T % temporal, axis=0)], axis=0)
+        T = frames_f32.shape[0]
+    gt, gh, gw = T // temporal, H // patch, W // patch
+    x = frames_f32.reshape(gt, temporal, C, gh // merge, merge, patch, gw // merge, merge, patch)
+    x = x.transpose(0, 3, 6, 4, 7, 2, 1, 5, 8)   # gt, gh/m, gw/m, m, m, C, tp, ph, pw
+    flat = x.reshape(gt * gh * gw, C * temporal * patch * patch)
+    return np.ascontiguousarray(flat), np.asarray([[gt, gh, gw]], dtype=np.int64)
 
 
 def patchify_frames(frames_f32, patch=14, merge=2, temporal=2):

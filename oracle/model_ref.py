@@ -212,19 +212,38 @@ def lm_head_weight(W, cfg):
     return W["lm_head.weight"]
 
 
-def embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, taps=None):
-    """TF:1206-1215: embedding gather then masked_scatter of the merged visual tokens."""
+def embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, taps=None, pixel_values_videos=None,
+                      video_grid_thw=None):
+    """TF:1206-1215: embedding gather, then masked_scatter of the merged image tokens at the image placeholders and of the
+    merged video tokens at the video placeholders (each modality runs the tower on its own rows, TF:1060-1092)."""
     emb = W["model.language_model.embed_tokens.weight"].to(dtype)
     x = emb[input_ids]
-    if pixel_values is not None:
-        _, vis = vit_forward(W, cfg, pixel_values, image_grid_thw, dtype, taps)
+    for pv, grid, tok, tag in ((pixel_values, image_grid_thw, cfg["image_token_id"], "vit_merged"),
+                               (pixel_values_videos, video_grid_thw, cfg["video_token_id"], "vit_merged_video")):
+        if pv is None:
+            continue
+        _, vis = vit_forward(W, cfg, pv, grid, dtype, taps)
         if taps is not None:
-            taps["vit_merged"] = vis.clone()
-        m = input_ids == cfg["image_token_id"]
-        assert int(m.sum()) == vis.shape[0], "image features and image tokens do not match"
+            taps[tag] = vis.clone()
+        m = input_ids == tok
+        assert int(m.sum()) == vis.shape[0], "visual features and placeholder tokens do not match"
         x = x.clone()
         x[m] = vis.to(dtype)
     return x
+
+
+def _positions(cfg, input_ids, attention_mask, image_grid_thw, video_grid_thw, second_per_grid_ts):
+    """3-D positions + rope deltas of a prompt (TF:1135-1181 compute_3d_position_ids over get_rope_index)."""
+    B = input_ids.shape[0]
+    if image_grid_thw is None and video_grid_thw is None:
+        p1 = (attention_mask.cumsum(-1) - 1).masked_fill(attention_mask == 0, 0)
+        return p1.unsqueeze(0).expand(3, -1, -1).contiguous(), torch.zeros(B, 1, dtype=torch.long)
+    types = index_ref.token_types(input_ids.numpy(), cfg["image_token_id"], cfg["video_token_id"])
+    pos, deltas = index_ref.rope_index(input_ids.numpy(), types, image_grid_thw, attention_mask.numpy(),
+                                       cfg["vision_config"]["spatial_merge_size"], video_grid_thw=video_grid_thw,
+                                       second_per_grid_ts=second_per_grid_ts,
+                                       tokens_per_second=cfg["vision_config"].get("tokens_per_second", 1))
+    return torch.from_numpy(pos), torch.from_numpy(deltas)
 
 
 # ----------------------------------------------------------------------------- logits processors
@@ -261,7 +280,7 @@ def top_p_warp(scores, top_p, min_keep=1, filter_value=-float("inf")):
 def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens,
              dtype=torch.float32, eos_token_ids=(), pad_token_id=0, rep_penalty=1.0,
              do_sample=False, temperature=1.0, top_p=1.0, generator=None, taps=None,
-             return_logits=False, top_k=0):
+             return_logits=False, top_k=0, pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None):
     """Greedy / sampled decode, TF:generation/utils.py:2783-2942 (_sample) over
     TF:modeling_qwen2_5_vl.py:1185-1253,1308-1402.  Returns ids [B, S+T] (and the fp32
     last-token logits per step when return_logits)."""
@@ -270,19 +289,11 @@ def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, ma
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
     attention_mask = torch.as_tensor(attention_mask, dtype=torch.long)
-    types = (input_ids == cfg["image_token_id"]).long()
-    merge = cfg["vision_config"]["spatial_merge_size"]
-    if pixel_values is not None:
-        pos, deltas = index_ref.rope_index(input_ids.numpy(), types.numpy(), np.asarray(image_grid_thw),
-                                           attention_mask.numpy(), merge)
-        pos, deltas = torch.from_numpy(pos), torch.from_numpy(deltas)
-    else:
-        p1 = (attention_mask.cumsum(-1) - 1).masked_fill(attention_mask == 0, 0)
-        pos = p1.unsqueeze(0).expand(3, -1, -1).contiguous()
-        deltas = torch.zeros(B, 1, dtype=torch.long)
+    pos, deltas = _positions(cfg, input_ids, attention_mask, None if pixel_values is None else image_grid_thw,
+                             None if pixel_values_videos is None else video_grid_thw, second_per_grid_ts)
     tc = cfg["text_config"]
     cache = KVCache(tc["num_hidden_layers"])
-    x = embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, taps)
+    x = embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, taps, pixel_values_videos, video_grid_thw)
     if taps is not None:
         taps["inputs_embeds"] = x.clone()
         taps["position_ids"] = pos.clone()
@@ -332,18 +343,19 @@ def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, ma
     return ids
 
 
-def full_logits(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, dtype=torch.float32):
+def full_logits(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, dtype=torch.float32, pixel_values_videos=None,
+                video_grid_thw=None, second_per_grid_ts=None):
     """model(input_ids, ...).logits [B,L,V] as R:grpo_trainer.py:375 calls it."""
     input_ids = torch.as_tensor(input_ids, dtype=torch.long)
     B, S = input_ids.shape
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
-    types = (input_ids == cfg["image_token_id"]).long()
-    pos, _ = index_ref.rope_index(input_ids.numpy(), types.numpy(), np.asarray(image_grid_thw),
-                                  np.asarray(attention_mask), cfg["vision_config"]["spatial_merge_size"])
+    attention_mask = torch.as_tensor(attention_mask, dtype=torch.long)
+    pos, _ = _positions(cfg, input_ids, attention_mask, None if pixel_values is None else image_grid_thw,
+                        None if pixel_values_videos is None else video_grid_thw, second_per_grid_ts)
     cache = KVCache(cfg["text_config"]["num_hidden_layers"])
-    x = embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype)
-    h = text_forward(W, cfg, x, torch.from_numpy(pos), torch.as_tensor(attention_mask), cache, dtype)
+    x = embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, None, pixel_values_videos, video_grid_thw)
+    h = text_forward(W, cfg, x, pos, attention_mask, cache, dtype)
     return F.linear(h, lm_head_weight(W, cfg).to(dtype))
 
 

@@ -185,27 +185,50 @@ def text_forward(W, cfg, inputs_embeds, position_ids, attention_mask_2d, cache, 
 
 
 def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, dtype=torch.float32,
-             pad_token_id=0, rep_penalty=1.0, return_logits=False, taps=None):
-    """Greedy decode (TF:generation/utils.py _sample over TF3:1260-1580)."""
+             pad_token_id=0, rep_penalty=1.0, return_logits=False, taps=None, pixel_values_videos=None, video_grid_thw=None):
+    """Greedy decode (TF:generation/utils.py _sample over TF3:1260-1580).  Video inputs (TF3:1170-1218): the tower runs on
+    the video rows on its own, its tokens go to the <|video_pad|> positions and its DeepStack features to the same
+    positions; with images AND videos the DeepStack rows are interleaved in sequence order (TF3:1198-1211).  Positions:
+    every frame of a video is its own [1,h,w] group (TF3:966-969)."""
     input_ids = torch.as_tensor(input_ids, dtype=torch.long)
     B, S = input_ids.shape
     attention_mask = torch.ones_like(input_ids) if attention_mask is None else torch.as_tensor(attention_mask, dtype=torch.long)
-    types = (input_ids == cfg["image_token_id"]).long()
     merge = cfg["vision_config"]["spatial_merge_size"]
     emb = W["model.language_model.embed_tokens.weight"].to(dtype)
     x = emb[input_ids]
     vmask, deep = None, None
-    if pixel_values is not None:
-        pos, deltas = index_ref.rope_index(input_ids.numpy(), types.numpy(), np.asarray(image_grid_thw), attention_mask.numpy(), merge)
+    if pixel_values is not None or pixel_values_videos is not None:
+        types = index_ref.token_types(input_ids.numpy(), cfg["image_token_id"], cfg["video_token_id"])
+        pos, deltas = index_ref.rope_index(input_ids.numpy(), types, None if pixel_values is None else np.asarray(image_grid_thw),
+                                           attention_mask.numpy(), merge,
+                                           video_grid_thw=None if pixel_values_videos is None else np.asarray(video_grid_thw),
+                                           split_video_frames=True)
         pos, deltas = torch.from_numpy(pos), torch.from_numpy(deltas)
-        _, vis, deep = vit_forward(W, cfg, pixel_values, image_grid_thw, dtype, taps)
-        if taps is not None:
-            taps["vit_merged"] = vis.clone()
-            taps["deepstack"] = [d.clone() for d in deep]
-        vmask = input_ids == cfg["image_token_id"]
-        assert int(vmask.sum()) == vis.shape[0]
         x = x.clone()
-        x[vmask] = vis.to(dtype)
+        vmask = torch.zeros_like(input_ids, dtype=torch.bool)
+        parts = []
+        for pv, grid, tok, tag in ((pixel_values, image_grid_thw, cfg["image_token_id"], ""),
+                                   (pixel_values_videos, video_grid_thw, cfg["video_token_id"], "_video")):
+            if pv is None:
+                continue
+            _, vis, dp = vit_forward(W, cfg, pv, grid, dtype, taps)
+            if taps is not None:
+                taps["vit_merged" + tag] = vis.clone()
+                taps["deepstack" + tag] = [d.clone() for d in dp]
+            m = input_ids == tok
+            assert int(m.sum()) == vis.shape[0]
+            x[m] = vis.to(dtype)
+            vmask |= m
+            parts.append((m, dp))
+        if len(parts) == 1:
+            deep = parts[0][1]
+        else:                                                     # TF3:1198-1211: joint rows in sequence order
+            deep = []
+            for j in range(len(parts[0][1])):
+                joint = parts[0][1][j].new_zeros(int(vmask.sum()), parts[0][1][j].shape[-1])
+                for m, dp in parts:
+                    joint[m[vmask]] = dp[j]
+                deep.append(joint)
     else:
         p1 = (attention_mask.cumsum(-1) - 1).masked_fill(attention_mask == 0, 0)
         pos, deltas = p1.unsqueeze(0).expand(3, -1, -1).contiguous(), torch.zeros(B, 1, dtype=torch.long)

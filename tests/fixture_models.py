@@ -180,6 +180,31 @@ def make_prompt(cfg, grids, n_text_pre=5, n_text_mid=3, n_text_post=6, seed=0):
     return ids
 
 
+def make_prompt_mm(cfg, items, n_text_pre=5, n_text_mid=3, n_text_post=6, seed=0, per_frame_video=False):
+    """Synthetic prompt with native video inputs.  items: [("image" | "video", (t, h, w))] in sequence order.  A video is ONE
+    run of t*h*w/4 <|video_pad|> tokens between <vs> / <ve> (Qwen2.5-VL, TF:models/qwen2_5_vl/processing_qwen2_5_vl.py:64-67);
+    per_frame_video (Qwen3-VL, TF:models/qwen3_vl/processing_qwen3_vl.py:80-106): every temporal patch is its own
+    [timestamp text.., <vs>, h*w/4 pads, <ve>] block."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    V = cfg["text_config"]["vocab_size"]
+    lo, hi = 10, min(V, cfg["vision_start_token_id"]) - 1
+    unit = cfg["vision_config"]["spatial_merge_size"] ** 2
+
+    def text(n):
+        return torch.randint(lo, hi, (n,), generator=g).tolist()
+
+    ids = text(n_text_pre)
+    for kind, (t, h, w) in items:
+        tok = cfg["image_token_id"] if kind == "image" else cfg["video_token_id"]
+        if kind == "video" and per_frame_video:
+            for _ in range(t):
+                ids += text(n_text_mid) + [cfg["vision_start_token_id"]] + [tok] * (h * w // unit) + [cfg["vision_end_token_id"]]
+        else:
+            ids += text(n_text_mid) + [cfg["vision_start_token_id"]] + [tok] * (t * h * w // unit) + [cfg["vision_end_token_id"]]
+    ids += text(n_text_post)
+    return ids
+
+
 def make_frames(n, H, W, seed=0):
     """uint8 RGB frames [n,3,H,W]."""
     g = torch.Generator().manual_seed(2000 + seed)

@@ -451,6 +451,164 @@ def g12_g13_qwen3vl():
             raise RuntimeError("no robust seed for " + tag)
 
 
+# ------------------------------------------------------------------------------------------------ G14 / G15 native video
+def _tf_video_patchify():
+    """Qwen2VLVideoProcessor.patchify (TF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274) compiled from the installed
+    library's source: its module imports torchvision at the top (absent here), the method itself is torch view / permute only."""
+    import ast
+    path = os.path.join(os.path.dirname(transformers.__file__), "models", "qwen2_vl", "video_processing_qwen2_vl.py")
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "Qwen2VLVideoProcessor":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == "patchify":
+                    fn.returns = None
+                    for a in fn.args.args:
+                        a.annotation = None
+                    ns = {"torch": torch}
+                    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+                    return ns["patchify"]
+    raise RuntimeError("Qwen2VLVideoProcessor.patchify not found")
+
+
+def preprocess_video(frames_u8, patch=14, mean=None, std=None):
+    """One video [T,3,H,W] uint8 -> (pixel_values_videos f32 [T/2*gh*gw, 3*2*p*p], video_grid_thw [[T/2, gh, gw]]).  Rescale +
+    normalise per frame with the PIL image processor's own methods (the arithmetic G3 pins for images; the torchvision
+    video backend, absent here, fuses the two steps and may differ in the last fp32 bit), then TF's video patchify."""
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    kw = {} if mean is None else dict(image_mean=mean, image_std=std)
+    ip = Qwen2VLImageProcessorPil(do_resize=False, patch_size=patch, **kw)
+    fr = [ip.normalize(ip.rescale(f.numpy(), ip.rescale_factor), ip.image_mean, ip.image_std) for f in frames_u8]
+    vid = torch.from_numpy(np.stack(fr).astype(np.float32))[None]
+    patches, gt, gh, gw = _tf_video_patchify()(None, vid, patch, 2, 2)
+    return patches[0].float().contiguous(), torch.tensor([[gt, gh, gw]], dtype=torch.long)
+
+
+def g5b_rope_index_video():
+    """get_rope_index with native video groups (TF:944-1058): temporal spacing tokens_per_second * int(second_per_grid_t),
+    several videos, video + image in one prompt, left padding; and Qwen3-VL's per-frame split (TF3:966-969)."""
+    cfg = fm.tiny_config()
+    m = hf_model(cfg, fm.make_weights(cfg, 0), torch.float32)
+    res = {}
+    cases = {
+        "v3": ([("video", (3, 4, 6))], [1.0], 0),
+        "v8_half": ([("video", (8, 6, 8))], [0.5], 0),           # int(0.5) = 0: all temporal positions equal
+        "v4_two": ([("video", (4, 4, 4))], [2.0], 0),
+        "v2v3": ([("video", (2, 4, 6)), ("video", (3, 6, 4))], [1.0, 3.0], 0),
+        "vi": ([("video", (3, 4, 6)), ("image", (1, 6, 8))], [1.0], 0),
+        "iv_pad": ([("image", (1, 4, 4)), ("video", (5, 8, 12))], [1.0], 5),
+        "v16_none": ([("video", (16, 16, 30))], None, 0),
+    }
+    import fixture_models_q3 as fq
+    m3 = hf_q3(fq.tiny_q3_config(), fq.make_weights(fq.tiny_q3_config(), 0), torch.float32)
+    for tag, (items, spg, left_pad) in cases.items():
+        for fam, model, c, per_frame in (("q25", m, cfg, False), ("q3", m3, fq.tiny_q3_config(), True)):
+            ids = fm.make_prompt_mm(c, items, seed=len(tag), per_frame_video=per_frame)
+            mask = [1] * len(ids)
+            if left_pad:
+                ids = [c["pad_token_id"]] * left_pad + ids
+                mask = [0] * left_pad + mask
+            ids_t, mask_t = torch.tensor([ids]), torch.tensor([mask])
+            types = (ids_t == c["image_token_id"]).int() + 2 * (ids_t == c["video_token_id"]).int()
+            ig = [g for k, g in items if k == "image"]
+            vg = [g for k, g in items if k == "video"]
+            kw = dict(mm_token_type_ids=types, image_grid_thw=torch.tensor(ig) if ig else None,
+                      video_grid_thw=torch.tensor(vg) if vg else None, attention_mask=mask_t)
+            if fam == "q25":
+                kw["second_per_grid_ts"] = None if spg is None else torch.tensor(spg)
+            pos, delta = model.model.get_rope_index(ids_t, **kw)
+            k = f"{fam}_{tag}"
+            res[k + "_ids"], res[k + "_mask"] = ids_t.numpy(), mask_t.numpy()
+            res[k + "_igrid"] = np.asarray(ig, dtype=np.int64).reshape(-1, 3)
+            res[k + "_vgrid"] = np.asarray(vg, dtype=np.int64).reshape(-1, 3)
+            res[k + "_spg"] = np.asarray([] if spg is None else spg, dtype=np.float64)
+            res[k + "_has_spg"] = np.asarray([spg is not None])
+            res[k + "_pos"], res[k + "_delta"] = pos.numpy(), delta.numpy()
+    res["tokens_per_second"] = np.asarray([cfg["vision_config"]["tokens_per_second"]])
+    np.savez_compressed(os.path.join(GOLD, "g5b_rope_index_video.npz"), **res)
+    print("G5b written", len(res))
+
+
+def video_case(fam, cfg, wseed, vframes, iframes, n_new, prompt_seed, spg):
+    """HF fp32 + bf16 greedy generation over a NATIVE video input (pixel_values_videos / video_grid_thw / <|video_pad|>), optionally
+    with an image after it (the layout R:eval/models/model_vllm.py:41-52 builds)."""
+    q3 = fam == "q3"
+    if q3:
+        import fixture_models_q3 as fq
+        W = fq.make_weights(cfg, wseed)
+        pvv, vgrid = preprocess_video(vframes, patch=16, mean=[0.5, 0.5, 0.5], std=[0.5, 0.5, 0.5])
+        pvi, igrid = preprocess_frames_q3(iframes) if iframes is not None else (None, None)
+    else:
+        W = fm.make_weights(cfg, wseed)
+        pvv, vgrid = preprocess_video(vframes)
+        pvi, igrid = preprocess_frames(iframes) if iframes is not None else (None, None)
+    items = [("video", tuple(vgrid[0].tolist()))] + ([("image", tuple(g)) for g in igrid.tolist()] if igrid is not None else [])
+    ids = fm.make_prompt_mm(cfg, items, seed=prompt_seed, per_frame_video=q3)
+    ids_t = torch.tensor([ids])
+    mask = torch.ones_like(ids_t)
+    types = (ids_t == cfg["image_token_id"]).int() + 2 * (ids_t == cfg["video_token_id"]).int()
+    res = {"video_frames": vframes.numpy(), "pixel_values_videos": pvv.numpy(), "video_grid": vgrid.numpy(), "input_ids": ids_t.numpy(),
+           "second_per_grid_ts": np.asarray(spg, dtype=np.float64)}
+    if iframes is not None:
+        res.update({"image_frames": iframes.numpy(), "pixel_values": pvi.numpy(), "image_grid": igrid.numpy()})
+    kw = dict(input_ids=ids_t, attention_mask=mask, pixel_values_videos=pvv, video_grid_thw=vgrid, mm_token_type_ids=types)
+    if iframes is not None:
+        kw.update(pixel_values=pvi, image_grid_thw=igrid)
+    if not q3:
+        kw["second_per_grid_ts"] = torch.tensor(spg)
+    for dname, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = hf_q3(cfg, W, dt) if q3 else hf_model(cfg, W, dt)
+        with torch.no_grad():
+            vo = m.model.visual(pvv.to(dt), grid_thw=vgrid)
+            pos, delta = m.model.get_rope_index(ids_t, mm_token_type_ids=types, image_grid_thw=igrid, video_grid_thw=vgrid,
+                                                attention_mask=mask, **({} if q3 else {"second_per_grid_ts": torch.tensor(spg)}))
+            out = m(**kw)
+            gen = m.generate(**kw, do_sample=False, max_new_tokens=n_new, output_logits=True, return_dict_in_generate=True,
+                             eos_token_id=None, pad_token_id=cfg["pad_token_id"], repetition_penalty=1.0, temperature=None,
+                             top_p=None, top_k=None)
+            gen_rp = m.generate(**kw, do_sample=False, max_new_tokens=n_new, eos_token_id=None, pad_token_id=cfg["pad_token_id"],
+                                repetition_penalty=1.05, temperature=None, top_p=None, top_k=None)
+        step_logits = torch.stack(gen.logits, dim=1).float()
+        top2 = step_logits.topk(2, dim=-1).values
+        res[f"{dname}_vit_merged_video"] = vo.pooler_output.float().numpy()
+        if q3:
+            for j, d in enumerate(vo.deepstack_features):
+                res[f"{dname}_deepstack_video_{j}"] = d.float().numpy()
+        res[f"{dname}_prefill_last_logits"] = out.logits[:, -1].float().numpy()
+        res[f"{dname}_ids"] = gen.sequences.numpy()
+        res[f"{dname}_ids_rp105"] = gen_rp.numpy()
+        res[f"{dname}_step_logits"] = step_logits.numpy()
+        res[f"{dname}_margins"] = (top2[..., 0] - top2[..., 1]).numpy()
+        res[f"{dname}_rope_deltas"] = m.model.rope_deltas.numpy()
+        res["position_ids"], res["rope_index_delta"] = pos.numpy(), delta.numpy()
+    return res
+
+
+def g14_g15_video():
+    import fixture_models_q3 as fq
+    specs = (
+        # tag, family, config, weight seed, video frames (n, H, W), image frames or None, new tokens, second_per_grid_ts, file
+        ("G14 tiny video", "q25", fm.tiny_config(), 0, (6, 56, 84), None, 12, [1.0], "g14_video_tiny.npz"),            # grid [3,4,6]
+        ("G14b medium video+image", "q25", fm.medium_config(), 2, (5, 112, 140), (1, 56, 84), 12, [2.0], "g14_video_medium.npz"),  # odd T -> [3,8,10]
+        ("G15 q3 tiny video", "q3", fq.tiny_q3_config(), 0, (4, 64, 96), None, 12, [1.0], "g15_q3_video_tiny.npz"),      # grid [2,4,6]
+        ("G15b q3 medium video+image", "q3", fq.medium_q3_config(), 2, (6, 128, 160), (1, 64, 96), 12, [1.0], "g15_q3_video_medium.npz"),
+    )
+    for tag, fam, cfg, wseed, (n, H, W), img, n_new, spg, fname in specs:
+        for s in range(200):
+            r = video_case(fam, cfg, wseed, fm.make_frames(n, H, W, seed=s), None if img is None else fm.make_frames(*img, seed=500 + s),
+                           n_new, s, spg)
+            ok = (r["f32_ids"] == r["bf16_ids"]).all() and min(r["f32_margins"].min(), r["bf16_margins"].min()) > 0.2 \
+                and (r["f32_ids_rp105"] == r["bf16_ids_rp105"]).all()
+            if ok:
+                r["case_seed"] = np.asarray([s])
+                np.savez_compressed(os.path.join(GOLD, fname), **r)
+                print(f"{tag}: seed {s} min margins {r['f32_margins'].min():.3f} / {r['bf16_margins'].min():.3f} ids {r['bf16_ids'][0, -n_new:]}",
+                      flush=True)
+                break
+        else:
+            raise RuntimeError("no robust seed for " + tag)
+
+
 def g8_logits_processors():
     from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
                                                         TopPLogitsWarper)
@@ -529,6 +687,10 @@ if __name__ == "__main__":
         g10_full_depth()
     if "g11" in which:
         g11_tied()
+    if "g5b" in which:
+        g5b_rope_index_video()
+    if "g14" in which:
+        g14_g15_video()
 
 
 # ------------------------------------------------------------------------------------------------ G9 rewards / spans
