@@ -76,6 +76,12 @@ int o3v_patchify(const void* frames, int is_u8, void* dst, int T, int H, int W, 
 /* The same for a `patch`-pixel patch (Qwen3-VL: 16; H, W multiples of 2*patch; Kp >= 6*patch*patch). */
 int o3v_patchify_ps(const void* frames, int is_u8, void* dst, int T, int H, int W, int Kp, int patch, const float* mean3,
                     const float* std3, o3v_stream_t stream);
+/* Native video input (the "video" entry of R:eval/models/model_vllm.py:72-88, pixel_values_videos of R:…/grpo_trainer.py:555-564):
+ * Qwen2VLVideoProcessor's patchify, TF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274 -- temporal patch k of the ONE
+ * video `frames` [n_frames,3,H,W] holds frames 2k and 2k+1 (an odd count repeats the last frame); dst bf16
+ * [ceil(n_frames/2)*(H/patch)*(W/patch), Kp], rows (grid_t, gh/2, gw/2, 2, 2), columns (channel, t, py, px). */
+int o3v_patchify_video(const void* frames, int is_u8, void* dst, int n_frames, int H, int W, int Kp, int patch,
+                       const float* mean3, const float* std3, o3v_stream_t stream);
 
 /* fetch_video's frame resize, R:src/r1-v/src/open_r1/vision_process.py:310-315 (torchvision resize, BICUBIC, antialias ==
  * ATen _upsample_bicubic2d_aa): src [planes,H_in,W_in] uint8 or f32 -> dst f32 [planes,H_out,W_out]; tmp f32

@@ -84,6 +84,7 @@ SIGNATURES = {
     "o3v_qkv_norm_rope_cache": [vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_add_rows": [vp, vp, vp, vp, i32, i32, vp],
     "o3v_patchify_ps": [vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp],
+    "o3v_patchify_video": [vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp],
     "o3v_vit_rope": [vp, vp, vp, i32, i32, i32, vp],
     "o3v_mrope_table": [vp, vp, vp, vp, vp, i32, i32, vp],
     "o3v_qkv_rope_cache": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -164,7 +165,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
             fn.argtypes = args
             fn.restype = _RET.get(name, i32)
-        if lib.o3v_abi_version() != 5:
+        if lib.o3v_abi_version() != 6:
             raise O3VError("libo3v_hip.so ABI version mismatch")
         _lib = lib
     return _lib

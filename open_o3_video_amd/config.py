@@ -28,6 +28,8 @@ class VisionCfg:
     num_position_embeddings: int = 0
     deepstack_visual_indexes: List[int] = field(default_factory=list)
     hidden_act: str = "silu"
+    # rope positions per second of video (TF:models/qwen2_5_vl/configuration_qwen2_5_vl.py:60; the 7B / 3B checkpoints say 2)
+    tokens_per_second: int = 4
 
     @property
     def head_dim(self):
@@ -120,7 +122,8 @@ class O3VConfig:
             deepstack_visual_indexes=list(vc.get("deepstack_visual_indexes", [8, 16, 24] if q3 else [])),
             hidden_act=vc.get("hidden_act", "gelu_pytorch_tanh" if q3 else "silu"), temporal_patch_size=vc.get("temporal_patch_size", 2),
             spatial_merge_size=vc.get("spatial_merge_size", 2), window_size=vc.get("window_size", 112),
-            fullatt_block_indexes=list(vc.get("fullatt_block_indexes", [7, 15, 23, 31])), in_channels=vc.get("in_channels", 3))
+            fullatt_block_indexes=list(vc.get("fullatt_block_indexes", [7, 15, 23, 31])), in_channels=vc.get("in_channels", 3),
+            tokens_per_second=int(vc.get("tokens_per_second", 4)))
         text = TextCfg(
             hidden_size=tc["hidden_size"], num_hidden_layers=tc["num_hidden_layers"],
             num_attention_heads=tc["num_attention_heads"], num_key_value_heads=tc["num_key_value_heads"],
@@ -156,7 +159,7 @@ def qwen25vl_7b_dict():
         "vision_end_token_id": 151653, "eos_token_id": 151645, "pad_token_id": 151643, "tie_word_embeddings": False,
         "vision_config": {"depth": 32, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420,
                           "out_hidden_size": 3584, "patch_size": 14, "temporal_patch_size": 2, "spatial_merge_size": 2,
-                          "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31], "in_channels": 3},
+                          "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31], "in_channels": 3, "tokens_per_second": 2},
         "text_config": {"hidden_size": 3584, "num_hidden_layers": 28, "num_attention_heads": 28, "num_key_value_heads": 4,
                         "intermediate_size": 18944, "vocab_size": 152064, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
                         "mrope_section": [16, 24, 24], "tie_word_embeddings": False},

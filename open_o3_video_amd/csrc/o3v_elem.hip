@@ -479,10 +479,12 @@ extern "C" int o3v_cast_pad_f32_bf16(const float* src, void* dst, int P, int K0,
 // TF:image_transforms.py:118 does), CLIP normalise (fp32), patchify to merge-block-major rows with the
 // temporal slice duplicated (TF:image_processing_pil_qwen2_vl.py:152-187), cast bf16, zero pad to Kp.
 // ------------------------------------------------------------------------------------------------
-template <typename TIN>
+// PAIRS (native video input, TF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274): temporal patch f holds frames 2f and
+// 2f+1 in its two temporal slices (an odd frame count repeats the last frame); T then counts temporal patches and NF frames.
+template <typename TIN, bool PAIRS>
 __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ frames, bf16_t* __restrict__ dst, int T,
                                                        int H, int W, int Kp, int PS, float m0, float m1, float m2, float s0,
-                                                       float s1, float s2) {
+                                                       float s1, float s2, int NF) {
     const int gh = H / PS, gw = W / PS, ppf = gh * gw, gwm = gw >> 1;
     const int cpr = Kp >> 3;
     const long total = (long)T * ppf * cpr;
@@ -504,9 +506,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ f
             float val = 0.f;
             if (k < 3 * 2 * PS * PS) {
                 int ch = k / (2 * PS * PS);
-                int rem = k % (PS * PS);  // temporal slice index dropped: both slices are the same frame
+                int rem = k % (PS * PS);  // images: temporal slice index dropped, both slices are the same frame
                 int py = rem / PS, px = rem % PS;
-                double raw = (double)frames[(((size_t)f * 3 + ch) * H + (prow * PS + py)) * W + (pcol * PS + px)];
+                int fr = f;
+                if (PAIRS) {
+                    fr = 2 * f + (k / (PS * PS)) % 2;
+                    if (fr > NF - 1) fr = NF - 1;
+                }
+                double raw = (double)frames[(((size_t)fr * 3 + ch) * H + (prow * PS + py)) * W + (pcol * PS + px)];
                 float r = (float)(raw * 0.00392156862745098);
                 float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
                 float sd = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
@@ -530,11 +537,31 @@ extern "C" int o3v_patchify_ps(const void* frames, int is_u8, void* dst, int T, 
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (is_u8)
-        O3V_KLAUNCH(patchify_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
-                           T, H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+        O3V_KLAUNCH((patchify_kernel<uint8_t, false>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
+                           T, H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], T);
     else
-        O3V_KLAUNCH(patchify_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
-                           H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+        O3V_KLAUNCH((patchify_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
+                           H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], T);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
+}
+
+extern "C" int o3v_patchify_video(const void* frames, int is_u8, void* dst, int n_frames, int H, int W, int Kp, int patch,
+                                  const float* mean3, const float* std3, hipStream_t stream) {
+    if (!frames || !dst || !mean3 || !std3 || n_frames < 0 || H <= 0 || W <= 0 || patch <= 0 || (H % (2 * patch)) ||
+        (W % (2 * patch)) || Kp < 6 * patch * patch || (Kp & 7))
+        return O3V_ERR_ARG;
+    if (n_frames == 0) return O3V_OK;
+    const int T = (n_frames + 1) / 2;
+    long total = (long)T * (H / patch) * (W / patch) * (Kp >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (is_u8)
+        O3V_KLAUNCH((patchify_kernel<uint8_t, true>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)frames, (bf16_t*)dst,
+                           T, H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], n_frames);
+    else
+        O3V_KLAUNCH((patchify_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, (const float*)frames, (bf16_t*)dst, T,
+                           H, W, Kp, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], n_frames);
     O3V_CHECK_LAUNCH();
     return O3V_OK;
 }

@@ -50,7 +50,7 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
-extern "C" int o3v_abi_version(void) { return 5; }
+extern "C" int o3v_abi_version(void) { return 6; }
 
 // ------------------------------------------------------------------------------------------------ context handle
 // Owning host-side copy of the descriptors ("no global mutable state except an explicit o3v_ctx").

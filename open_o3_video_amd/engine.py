@@ -70,6 +70,9 @@ class O3VEngine:
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
         self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
+        # video rope arithmetic (indexing.rope_index): "tf5" = transformers 5.15 (goldens G5b / G14 / G15), "pinned" = the
+        # libraries the reference installs (transformers @336dc69d, vllm 0.7.2).  The facades choose; images do not depend on it.
+        self.position_mode = "tf5"
 
     # ------------------------------------------------------------------------------------------ vision
     def _vit_plan(self, grid_thw):
@@ -154,6 +157,25 @@ class O3VEngine:
         grid = np.asarray([[1, H // ps, W // ps]] * T, dtype=np.int64)
         return out, grid
 
+    def pixels_from_video(self, frames: torch.Tensor):
+        """ONE native video [T,3,H,W] uint8 or f32 (0..255) -> (bf16 [ceil(T/2)*gh*gw, Kp], grid [[ceil(T/2), gh, gw]]): temporal
+        patch k holds frames 2k and 2k+1, an odd count repeats the last frame (TF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274;
+        R:src/r1-v/src/open_r1/vision_process.py:319-333 pads frame lists the same way)."""
+        vc = self.cfg.vision
+        if frames.dim() != 4 or frames.shape[1] != 3 or frames.shape[0] == 0:
+            raise ValueError("video frames must be [T,3,H,W] with T >= 1")
+        T, _, H, W = frames.shape
+        ps = vc.patch_size
+        if H % (2 * ps) or W % (2 * ps):
+            raise ValueError(f"frame size must be a multiple of {2 * ps} (smart_resize output)")
+        is_u8 = frames.dtype == torch.uint8
+        fr = frames.to(self.dev).contiguous() if is_u8 else frames.to(self.dev, torch.float32).contiguous()
+        gt = (T + 1) // 2
+        out = torch.empty((gt * (H // ps) * (W // ps), vc.patch_k_pad), dtype=torch.bfloat16, device=self.dev)
+        _lib.call("o3v_patchify_video", _ptr(fr), int(is_u8), _ptr(out), T, H, W, vc.patch_k_pad, ps, self.clip_mean, self.clip_std,
+                  _stream())
+        return out, np.asarray([[gt, H // ps, W // ps]], dtype=np.int64)
+
     def vit_forward(self, pixels_bf16: torch.Tensor, grid_thw) -> torch.Tensor:
         """TF:408-471 -> merged visual tokens bf16 [P/4, out_hidden] in original order."""
         vc = self.cfg.vision
@@ -191,14 +213,18 @@ class O3VEngine:
         _lib.call("o3v_mrope_table", _ptr(p), _ptr(self.inv_freq), _ptr(self.axis_of), _ptr(cos), _ptr(sin), T, D, _stream())
         return cos, sin
 
-    def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor], first: int = 0) -> torch.Tensor:
-        """inputs_embeds of the (flattened) prompt; `first` > 0 returns only rows first.. (prefix-KV reuse)."""
-        src, n_img = indexing.embed_source_rows(input_ids, self.cfg.image_token_id)
+    def embed(self, input_ids: np.ndarray, vis: Optional[torch.Tensor], first: int = 0, n_image_rows: Optional[int] = None) -> torch.Tensor:
+        """inputs_embeds of the (flattened) prompt; `first` > 0 returns only rows first.. (prefix-KV reuse).  `vis` holds the
+        image tokens followed by the video tokens (n_image_rows of the former; default: as many as image placeholders)."""
+        src, n_img, n_vid = indexing.embed_source_rows(input_ids, self.cfg.image_token_id, self.cfg.video_token_id, n_image_rows)
         if vis is not None and vis.dim() == 3:      # Qwen3-VL: [1 + n_deep, n, H], block 0 = the visual tokens
             vis = vis[0]
-        if n_img and (vis is None or vis.shape[0] != n_img):
-            raise ValueError(f"Image features and image tokens do not match, tokens: {n_img}, "
-                             f"features: {0 if vis is None else vis.shape[0]}")
+        n_rows = 0 if vis is None else vis.shape[0]
+        n_img_rows = n_img if n_image_rows is None else int(n_image_rows)
+        if n_img != n_img_rows or n_img + n_vid != n_rows:
+            what = "Video" if n_img == n_img_rows else "Image"
+            raise ValueError(f"{what} features and {what.lower()} tokens do not match, tokens: {n_img} image + {n_vid} video, "
+                             f"features: {n_img_rows} image + {n_rows - n_img_rows} video")
         src = src[first:]
         H = self.cfg.text.hidden_size
         T = src.shape[0]
@@ -206,6 +232,45 @@ class O3VEngine:
         s = torch.from_numpy(src).to(self.dev)
         _lib.call("o3v_embed_scatter", _ptr(self.w.t["l.embed"]), _ptr(vis), _ptr(s), _ptr(x), T, H, _stream())
         return x
+
+    def _visual(self, pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw, video_frames):
+        """The visual side of a call -> (vis, image grid, video grid, n_image_rows): image tokens first, video tokens after them
+        (each modality is scattered to its own placeholders in order, TF:1206-1215; the tower treats every temporal patch as its
+        own attention segment either way, TF:vision_utils.py:60-65, so the two runs are independent)."""
+        as_np = lambda g: None if g is None else np.asarray(g.cpu() if torch.is_tensor(g) else g, dtype=np.int64).reshape(-1, 3)
+        grid, vgrid = as_np(image_grid_thw), as_np(video_grid_thw)
+        if vis_embeds is not None:
+            n_img = None if vgrid is None else (0 if grid is None else int((grid.prod(axis=1) // self.cfg.vision.merge_unit).sum()))
+            return vis_embeds, grid, vgrid, n_img
+        parts = []
+        if frames is not None:
+            px, grid = self.pixels_from_frames(frames)
+            parts.append(self.vit_forward(px, grid))
+        elif pixel_values is not None:
+            parts.append(self.vit_forward(self.pixels_from_processor(pixel_values), grid))
+        n_img = None
+        if video_frames is not None or pixel_values_videos is not None:
+            n_img = parts[0].shape[-2] if parts else 0
+            if video_frames is not None:
+                vids = video_frames if isinstance(video_frames, (list, tuple)) else [video_frames]
+                px_g = [self.pixels_from_video(v) for v in vids]
+                px, vgrid = torch.cat([p for p, _ in px_g]), np.concatenate([g for _, g in px_g])
+            else:
+                px = self.pixels_from_processor(pixel_values_videos)
+            parts.append(self.vit_forward(px, vgrid))
+        if not parts:
+            return None, None, None, None
+        return (parts[0] if len(parts) == 1 else torch.cat(parts, dim=-2)), grid, vgrid, n_img
+
+    def _positions(self, ids, mask, grid, vgrid, second_per_grid_ts):
+        cfg = self.cfg
+        if grid is None and vgrid is None:
+            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
+            return np.broadcast_to(p1[None], (3,) + ids.shape).copy(), np.zeros(ids.shape[0], dtype=np.int64)
+        return indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size, video_grid_thw=vgrid,
+                                   video_token_id=cfg.video_token_id, second_per_grid_ts=second_per_grid_ts,
+                                   tokens_per_second=cfg.vision.tokens_per_second, split_video_frames=self.q3,
+                                   mode="tf5" if self.q3 else self.position_mode)
 
     def alloc_cache(self, B, Tmax):
         tc = self.cfg.text
@@ -230,7 +295,7 @@ class O3VEngine:
         keep = []
         if deepstack is not None and deepstack[1] is not None and deepstack[1].dim() == 3 and deepstack[1].shape[0] > 1:
             ids_all, vis = deepstack
-            rows, src = indexing.deepstack_rows(ids_all, self.cfg.image_token_id, first=past)
+            rows, src = indexing.deepstack_rows(ids_all, self.cfg.image_token_id, first=past, video_token_id=self.cfg.video_token_id)
             rows_d, src_d = torch.from_numpy(rows).to(self.dev), torch.from_numpy(src).to(self.dev)
             feat = vis[1:]
             keep += [rows_d, src_d, feat]
@@ -263,7 +328,8 @@ class O3VEngine:
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  top_k: int = 0, num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
                  vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 16, return_margins: bool = True,
-                 sync_timings: bool = False, prefix_key=None) -> GenerateOutput:
+                 sync_timings: bool = False, prefix_key=None, pixel_values_videos=None, video_grid_thw=None, video_frames=None,
+                 second_per_grid_ts=None) -> GenerateOutput:
         """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
         completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out.
 
@@ -299,23 +365,13 @@ class O3VEngine:
                 ev[i].record()
 
         mark(0)
-        # ---- vision (once per prompt batch)
-        vis = vis_embeds
-        grid = None if image_grid_thw is None else np.asarray(
-            image_grid_thw.cpu() if torch.is_tensor(image_grid_thw) else image_grid_thw, dtype=np.int64)
-        if vis is None:
-            if frames is not None:
-                px, grid = self.pixels_from_frames(frames)
-                vis = self.vit_forward(px, grid)
-            elif pixel_values is not None:
-                vis = self.vit_forward(self.pixels_from_processor(pixel_values), grid)
+        # ---- vision (once per prompt batch): images (frames-as-images, R:…/grpo_trainer.py:540-548) and / or native videos
+        # (pixel_values_videos + <|video_pad|>, R:…:555-564; R:eval/models/model_vllm.py:72-88)
+        vis, grid, vgrid, n_img_rows = self._visual(pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw,
+                                                    video_frames)
         mark(1)
         # ---- positions + prefill (once per prompt)
-        if grid is not None:
-            pos, deltas = indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size)
-        else:
-            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
-            pos, deltas = np.broadcast_to(p1[None], (3, B0, S)).copy(), np.zeros(B0, dtype=np.int64)
+        pos, deltas = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
         # G completions of a prompt share its K/V (head_dim 128, own keys in <= 32 splits): the prompt's K/V is kept ONCE
         # (kc0 / vc0) and every row's cache holds only its generated tokens -- no G-fold copy of the prompt
         own_splits = (T + 127) // 128
@@ -327,7 +383,7 @@ class O3VEngine:
         use_prefix = prefix_key is not None and B0 == 1 and int(pad[0]) == 0
         if use_prefix:
             past = self._prefix_lookup(prefix_key, ids[0])
-        x = self.embed(ids, vis, first=past)
+        x = self.embed(ids, vis, first=past, n_image_rows=n_img_rows)
         ds = (ids, vis) if self.q3 else None
         if G == 1 and not use_prefix:
             self.prefill(x, pos, pad, B0, S, kc, vc, deepstack=ds)
@@ -494,36 +550,26 @@ class O3VEngine:
     # ------------------------------------------------------------------------------------------ logits / logps
     @torch.no_grad()
     def forward_logits(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
-                       vis_embeds=None) -> torch.Tensor:
+                       vis_embeds=None, pixel_values_videos=None, video_grid_thw=None, video_frames=None,
+                       second_per_grid_ts=None) -> torch.Tensor:
         """model(input_ids, ...).logits bf16 [B,L,V] (R:grpo_trainer.py:375)."""
-        cfg = self.cfg
         ids = np.asarray(input_ids.cpu() if torch.is_tensor(input_ids) else input_ids, dtype=np.int64)
         B, S = ids.shape
         mask = np.ones_like(ids) if attention_mask is None else np.asarray(
             attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=np.int64)
         pad = (mask == 0).sum(axis=1)
-        grid = None if image_grid_thw is None else np.asarray(
-            image_grid_thw.cpu() if torch.is_tensor(image_grid_thw) else image_grid_thw, dtype=np.int64)
-        vis = vis_embeds
-        if vis is None:
-            if frames is not None:
-                px, grid = self.pixels_from_frames(frames)
-                vis = self.vit_forward(px, grid)
-            elif pixel_values is not None:
-                vis = self.vit_forward(self.pixels_from_processor(pixel_values), grid)
-        if grid is not None:
-            pos, _ = indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size)
-        else:
-            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
-            pos = np.broadcast_to(p1[None], (3, B, S)).copy()
+        vis, grid, vgrid, n_img_rows = self._visual(pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw,
+                                                    video_frames)
+        pos, _ = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
         kc, vc = self.alloc_cache(B, S)
-        x = self.embed(ids, vis)
+        x = self.embed(ids, vis, n_image_rows=n_img_rows)
         self.prefill(x, pos, pad, B, S, kc, vc, deepstack=(ids, vis) if self.q3 else None)
         return self.head(x).view(B, S, -1)
 
     @torch.no_grad()
     def completion_logps(self, prompt_ids, completion_ids, attention_mask=None, pixel_values=None, image_grid_thw=None,
-                         frames=None, vis_embeds=None, rows_per_chunk: int = 2048) -> torch.Tensor:
+                         frames=None, vis_embeds=None, rows_per_chunk: int = 2048, pixel_values_videos=None, video_grid_thw=None,
+                         video_frames=None, second_per_grid_ts=None) -> torch.Tensor:
         """log p(completion token | everything before it) for the G completions of ONE prompt -> f32 [G, T].
 
         What R:grpo_trainer.py:371-384 + :612-613 compute (`_get_per_token_logps(model, prompt_completion_ids, ...)
@@ -544,27 +590,16 @@ class O3VEngine:
         pad = (mask == 0).sum(axis=1)
         if not (mask[0, pad[0]:] == 1).all():
             raise ValueError("only left padding is supported (padding_side='left', R:grpo_trainer.py:546)")
-        grid = None if image_grid_thw is None else np.asarray(
-            image_grid_thw.cpu() if torch.is_tensor(image_grid_thw) else image_grid_thw, dtype=np.int64)
-        vis = vis_embeds
-        if vis is None:
-            if frames is not None:
-                px, grid = self.pixels_from_frames(frames)
-                vis = self.vit_forward(px, grid)
-            elif pixel_values is not None:
-                vis = self.vit_forward(self.pixels_from_processor(pixel_values), grid)
-        if grid is not None:
-            pos, deltas = indexing.rope_index(ids, mask, grid, cfg.image_token_id, cfg.vision.spatial_merge_size)
-        else:
-            p1 = np.where(mask == 0, 0, np.cumsum(mask, axis=1) - 1)
-            pos, deltas = np.broadcast_to(p1[None], (3, 1, S)).copy(), np.zeros(1, dtype=np.int64)
+        vis, grid, vgrid, n_img_rows = self._visual(pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw,
+                                                    video_frames)
+        pos, deltas = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
         H = tc.hidden_size
         out = torch.empty((G, T), dtype=torch.float32, device=self.dev)
         if T == 0 or G == 0:
             return out
         # prompt once
         kc0, vc0 = self.alloc_cache(1, S)
-        x = self.embed(ids, vis)
+        x = self.embed(ids, vis, n_image_rows=n_img_rows)
         self.prefill(x, pos, pad, 1, S, kc0, vc0, deepstack=(ids, vis) if self.q3 else None)
         x_last = x[S - 1:S].clone()                               # hidden state that predicts completion token 0
         del x

@@ -97,6 +97,9 @@ class Qwen2_5_VLForConditionalGeneration:
         # how a passed GenerationConfig is completed from the checkpoint's (resolve_generation_config): "pinned" = the library
         # version the reference installs, "tf5" = transformers >= 5
         self.generation_config_mode = "pinned"
+        # video rope arithmetic (indexing.rope_index mode): "pinned" = transformers @336dc69d as the reference installs it
+        # (R:setup.sh:4; restated, parity unpinned), "tf5" = transformers 5.15 (goldens G5b / G14 / G15).  Images do not depend on it.
+        self.position_mode = "pinned"
 
     # ---- construction
     @classmethod
@@ -143,9 +146,13 @@ class Qwen2_5_VLForConditionalGeneration:
     # ---- generate
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
-                 pixel_values_videos=None, video_grid_thw=None, generation_config=None, **kw):
-        if pixel_values is None and pixel_values_videos is not None:
-            pixel_values, image_grid_thw = self._video_as_images(pixel_values_videos, video_grid_thw)
+                 pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None, generation_config=None, **kw):
+        """`unwrapped_model.generate(**prompt_inputs, generation_config=...)` (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:581-582)
+        over either processor output: frames as images (`pixel_values` / `image_grid_thw`, :540-548) or the native video branch
+        (`pixel_values_videos` / `video_grid_thw` / `second_per_grid_ts` with <|video_pad|> prompts, :555-564), or both."""
+        ids = torch.as_tensor(input_ids).cpu().numpy()
+        pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw = self._route_video(
+            ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw)
         r = resolve_generation_config(generation_config, self.generation_config, kw, self.generation_config_mode)
         G, T, do_sample = int(r["num_return_sequences"]), int(r["max_new_tokens"]), bool(r["do_sample"])
         eos = r["eos_token_id"]
@@ -161,12 +168,9 @@ class Qwen2_5_VLForConditionalGeneration:
                       do_sample=do_sample, temperature=float(r["temperature"] or 1.0), top_p=float(r["top_p"] or 1.0),
                       top_k=top_k, seed=self._seed)
         self._seed += 1
-        ids = torch.as_tensor(input_ids).cpu().numpy()
-        self._check_no_video_tokens(ids)
         B = ids.shape[0]
         mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
-        grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()
-        per_prompt_pixels = self._split_pixels(ids, pixel_values, grid)
+        per_prompt = self._split_inputs(ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
         rows = []
         if G > MAX_ROWS:
             raise ValueError(f"num_return_sequences={G} > {MAX_ROWS}")
@@ -174,43 +178,73 @@ class Qwen2_5_VLForConditionalGeneration:
         # first global completion index of this call: a rank that decodes rows row0..row0+G-1 of a larger group keys its
         # sampler by those indices, so the group is the same whichever ranks produced its rows (partitioning B)
         row0 = int(kw.get("row_id_offset", getattr(generation_config, "row_id_offset", 0) or 0))
+        self.engine.position_mode = self.position_mode
         for b0 in range(0, B, step):
             b1 = min(B, b0 + step)
-            pv, gr = self._cat_pixels(per_prompt_pixels[b0:b1])
-            out = self.engine.generate(ids[b0:b1], None if mask is None else mask[b0:b1], pixel_values=pv, image_grid_thw=gr,
-                                       num_return_sequences=G, row_ids=list(range(row0 + b0 * G, row0 + b1 * G)), return_margins=False,
-                                       **common)
+            out = self.engine.generate(ids[b0:b1], None if mask is None else mask[b0:b1], num_return_sequences=G,
+                                       row_ids=list(range(row0 + b0 * G, row0 + b1 * G)), return_margins=False,
+                                       **self._cat_inputs(per_prompt[b0:b1]), **common)
             rows.append(out.sequences)
         L = max(r.shape[1] for r in rows)
         rows = [torch.nn.functional.pad(r, (0, L - r.shape[1]), value=pad) for r in rows]
         return torch.cat(rows, dim=0)
 
-    def _video_as_images(self, pixel_values_videos, video_grid_thw):
-        """The non-multi-image branch of the trainer hands the processor's video tensors over
-        (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:555-564, :604-606).  A video grid [t, h, w] holds t temporal patches of
-        two frames each; its pixel rows are t consecutive blocks of h*w patches, each exactly what an image of grid [1, h, w]
-        would hold, so the rows run through the same engine path as t images -- PROVIDED the prompt marks them with the image
-        placeholder: <|video_pad|> prompts get different rope positions (TF:892-942 advances time per temporal patch with
-        second_per_grid_ts) which this engine does not build."""
+    def _route_video(self, ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw):
+        """Video tensors behind <|video_pad|> placeholders run the native video path.  Video tensors whose prompt marks the frames
+        with IMAGE placeholders (no <|video_pad|> at all, every grid row t = 1) are the frames-as-images layout under another
+        argument name and take the image path."""
+        if pixel_values_videos is None:
+            if (ids == self.o3v_config.video_token_id).any():
+                raise ValueError("Video features and video tokens do not match, tokens: "
+                                 f"{int((ids == self.o3v_config.video_token_id).sum())}, features: 0")
+            return pixel_values, image_grid_thw, None, None
         if video_grid_thw is None:
             raise ValueError("pixel_values_videos needs video_grid_thw")
-        g = torch.as_tensor(video_grid_thw).cpu().numpy().reshape(-1, 3)
-        grid = np.concatenate([np.tile(np.asarray([[1, h, w]], dtype=np.int64), (int(t), 1)) for t, h, w in g], axis=0)
-        return pixel_values_videos, grid
+        if pixel_values is None and not (ids == self.o3v_config.video_token_id).any():
+            g = torch.as_tensor(video_grid_thw).cpu().numpy().reshape(-1, 3)
+            if (g[:, 0] == 1).all():
+                return pixel_values_videos, g, None, None
+        return pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw
 
-    def _check_no_video_tokens(self, ids):
-        if (ids == self.o3v_config.video_token_id).any():
-            raise NotImplementedError("prompts with <|video_pad|> placeholders are not supported: the reference feeds frames "
-                                      "as images (R:grpo_trainer.py:540-548); expand the video into <|image_pad|> runs")
+    def _split_inputs(self, ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts):
+        """Per prompt: dict(pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts) -- placeholders
+        of each modality consume that modality's grid rows in order."""
+        cfg = self.o3v_config
+        np_grid = lambda g: None if g is None else torch.as_tensor(g).cpu().numpy().reshape(-1, 3)
+        img = self._split_pixels(ids, pixel_values, np_grid(image_grid_thw), cfg.image_token_id)
+        vid = self._split_pixels(ids, pixel_values_videos, np_grid(video_grid_thw), cfg.video_token_id)
+        spg = None if second_per_grid_ts is None else [float(v) for v in torch.as_tensor(second_per_grid_ts).reshape(-1).tolist()]
+        out, vi = [], 0
+        for (pv, gr), (pvv, vgr) in zip(img, vid):
+            nv = 0 if vgr is None else len(vgr)
+            # Qwen3-VL counts one grid row per VIDEO although its prompt holds one placeholder run per temporal patch
+            out.append(dict(pixel_values=pv, image_grid_thw=gr, pixel_values_videos=pvv, video_grid_thw=vgr,
+                            second_per_grid_ts=None if spg is None or not nv else spg[vi:vi + nv]))
+            vi += nv
+        return out
 
-    def _split_pixels(self, ids, pixel_values, grid):
-        """Pixel rows / grid rows belonging to each prompt (placeholders are consumed in order)."""
+    @staticmethod
+    def _cat_inputs(parts):
+        kw = {}
+        for pk, gk in (("pixel_values", "image_grid_thw"), ("pixel_values_videos", "video_grid_thw")):
+            pvs = [p[pk] for p in parts if p[pk] is not None and len(p[pk])]
+            if pvs:
+                kw[pk] = torch.cat(pvs, dim=0)
+                kw[gk] = np.concatenate([p[gk] for p in parts if p[pk] is not None and len(p[pk])], axis=0)
+        if "pixel_values_videos" in kw:
+            sp = [p["second_per_grid_ts"] for p in parts if p["pixel_values_videos"] is not None and len(p["pixel_values_videos"])]
+            if all(x is not None for x in sp):
+                kw["second_per_grid_ts"] = [v for x in sp for v in x]
+        return kw
+
+    def _split_pixels(self, ids, pixel_values, grid, token_id):
+        """Pixel rows / grid rows belonging to each prompt (placeholders of `token_id` are consumed in order)."""
         B = ids.shape[0]
         if pixel_values is None or grid is None:
             return [(None, None)] * B
         unit = self.o3v_config.vision.merge_unit
         tok_per_img = (grid[:, 0] * grid[:, 1] * grid[:, 2]) // unit
-        n_tok = (ids == self.o3v_config.image_token_id).sum(axis=1)
+        n_tok = (ids == token_id).sum(axis=1)
         out, gi, prow = [], 0, 0
         pv = torch.as_tensor(pixel_values)
         for b in range(B):
@@ -226,59 +260,58 @@ class Qwen2_5_VLForConditionalGeneration:
             rows_n = int((grid[g0:gi, 0] * grid[g0:gi, 1] * grid[g0:gi, 2]).sum())
             out.append((pv[prow:prow + rows_n], grid[g0:gi]))
             prow += rows_n
+        if gi != len(grid):
+            raise ValueError("Image features and image tokens do not match")
         return out
-
-    @staticmethod
-    def _cat_pixels(parts):
-        pvs = [p for p, _ in parts if p is not None and len(p)]
-        if not pvs:
-            return None, None
-        return torch.cat(pvs, dim=0), np.concatenate([g for p, g in parts if p is not None and len(p)], axis=0)
 
     # ---- forward (logits), as _get_per_token_logps calls it
     @torch.no_grad()
     def __call__(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, pixel_values_videos=None,
-                 video_grid_thw=None, **kw):
-        if pixel_values is None and pixel_values_videos is not None:
-            pixel_values, image_grid_thw = self._video_as_images(pixel_values_videos, video_grid_thw)
+                 video_grid_thw=None, second_per_grid_ts=None, **kw):
         ids = torch.as_tensor(input_ids).cpu().numpy()
-        self._check_no_video_tokens(ids)
+        pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw = self._route_video(
+            ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw)
         B = ids.shape[0]
         mask = None if attention_mask is None else torch.as_tensor(attention_mask).cpu().numpy()
-        grid = None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy()
-        parts = self._split_pixels(ids, pixel_values, grid)
+        parts = self._split_inputs(ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
+        self.engine.position_mode = self.position_mode
         outs = []
         for b in range(B):  # one prompt at a time keeps the [L, V] logits slab bounded (7B: 1.4 GB per 4.6k tokens)
-            pv, gr = parts[b]
-            outs.append(self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], pixel_values=pv,
-                                                   image_grid_thw=gr))
+            outs.append(self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], **self._cat_inputs(parts[b:b + 1])))
         return SimpleNamespace(logits=torch.cat(outs, dim=0))
 
     forward = __call__
 
     @torch.no_grad()
-    def per_token_logps(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None):
+    def per_token_logps(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, pixel_values_videos=None,
+                        video_grid_thw=None, second_per_grid_ts=None):
         """Fast path for R:grpo_trainer.py:371-384: never keeps more than one row of logits alive."""
         ids = torch.as_tensor(input_ids)
+        ids_np = ids.cpu().numpy()
         out = []
         mask = None if attention_mask is None else torch.as_tensor(attention_mask)
-        parts = self._split_pixels(ids.cpu().numpy(), pixel_values,
-                                   None if image_grid_thw is None else torch.as_tensor(image_grid_thw).cpu().numpy())
+        pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw = self._route_video(
+            ids_np, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw)
+        parts = self._split_inputs(ids_np, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
+        self.engine.position_mode = self.position_mode
         for b in range(ids.shape[0]):
-            pv, gr = parts[b]
-            lg = self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], pixel_values=pv,
-                                            image_grid_thw=gr)
+            lg = self.engine.forward_logits(ids[b:b + 1], None if mask is None else mask[b:b + 1], **self._cat_inputs(parts[b:b + 1]))
             out.append(self.engine.per_token_logps(lg, ids[b:b + 1]))
         return torch.cat(out, dim=0)
 
-
     @torch.no_grad()
-    def completion_logps(self, prompt_ids, prompt_mask, completion_ids, pixel_values=None, image_grid_thw=None):
+    def completion_logps(self, prompt_ids, prompt_mask, completion_ids, pixel_values=None, image_grid_thw=None,
+                         pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None):
         """`_get_per_token_logps(model, cat([prompt]*G, completions), ...)[:, prompt_length-1:]` (R:grpo_trainer.py:371-384,
         :612-613) for the G completions of one prompt, f32 [G, T]: one ViT pass, one prompt prefill, logits only where kept
-        (see O3VEngine.completion_logps)."""
+        (see O3VEngine.completion_logps).  The trainer drops `second_per_grid_ts` before this pass (R:…:608-609): None = 1 s."""
+        ids = torch.as_tensor(prompt_ids).cpu().numpy().reshape(1, -1)
+        pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw = self._route_video(
+            ids, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw)
+        self.engine.position_mode = self.position_mode
         return self.engine.completion_logps(prompt_ids, completion_ids, prompt_mask, pixel_values=pixel_values,
-                                            image_grid_thw=image_grid_thw)
+                                            image_grid_thw=image_grid_thw, pixel_values_videos=pixel_values_videos,
+                                            video_grid_thw=video_grid_thw, second_per_grid_ts=second_per_grid_ts)
 
 
 # the north-star text names the Qwen2-VL class; both resolve to the same engine

@@ -83,58 +83,88 @@ def prefill_tiles(B, S, pad, tile=PREFILL_TILE, past=0):
     return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
 
-def rope_index(input_ids, attention_mask, image_grid_thw, image_token_id, merge=2):
-    """3-D M-RoPE positions for frames-as-images prompts.  Returns (pos [3,B,S] i64, deltas [B] i64, max_pos [B]).
+def rope_index(input_ids, attention_mask, image_grid_thw, image_token_id, merge=2, video_grid_thw=None, video_token_id=None,
+               second_per_grid_ts=None, tokens_per_second=1, split_video_frames=False, mode="tf5"):
+    """3-D M-RoPE positions (TF:944-1058 over TF:892-942).  Returns (pos [3,B,S] i64, deltas [B] i64).
 
     Text run: arange + cur on all three axes.  Image of (t,h,w): t-axis = cur (+frame index), h-axis = cur + row,
-    w-axis = cur + col over the merged (h/2, w/2) grid, then cur += max(h, w)/2  (TF:1033-1052)."""
+    w-axis = cur + col over the merged (h/2, w/2) grid.  Video (a run of `video_token_id`, grids from `video_grid_thw`): the
+    t-axis advances per temporal patch by the seconds it spans (`second_per_grid_ts`, 1 when None) times `tokens_per_second`.
+    split_video_frames (Qwen3-VL, TF3:966-969): every temporal patch of a video is its own [1,h,w] block (timestamps in text
+    separate them), no temporal scaling.
+
+    mode -- the two published forms of the video arithmetic (identical for images and for t = 1):
+      "tf5"    transformers 5.15 (goldens G5b / G14 / G15): step = tokens_per_second * int(second_per_grid_t) and the next
+               block starts max(h, w)/merge after this one whatever the temporal extent;
+      "pinned" the libraries the reference installs (transformers @336dc69d, R:setup.sh:4, and vllm 0.7.2's
+               MRotaryEmbedding.get_input_positions, R:setup.sh:7): t = trunc(k * second_per_grid_t * tokens_per_second) and the
+               next block starts at max(all three axes) + 1.  Restated from those releases' published algorithm (neither is
+               installed): parity unpinned."""
+    if mode not in ("tf5", "pinned"):
+        raise ValueError(f"mode={mode!r}: 'tf5' or 'pinned'")
     ids = np.asarray(input_ids)
     B, S = ids.shape
     mask = np.ones_like(ids) if attention_mask is None else np.asarray(attention_mask)
-    grids = [tuple(int(v) for v in g) for g in np.asarray(image_grid_thw).reshape(-1, 3)] if image_grid_thw is not None else []
+    as_grids = lambda g: [] if g is None else [tuple(int(v) for v in r) for r in np.asarray(g).reshape(-1, 3)]
+    grids = {1: as_grids(image_grid_thw), 2: as_grids(video_grid_thw)}
+    if split_video_frames:
+        grids[2] = [(1, h, w) for (t, h, w) in grids[2] for _ in range(t)]
+    spg = None if second_per_grid_ts is None else [float(v) for v in np.asarray(second_per_grid_ts, dtype=np.float64).reshape(-1)]
+    gi = {1: 0, 2: 0}
+    vi = 0                                              # videos seen: indexes second_per_grid_ts
     pos = np.zeros((3, B, S), dtype=np.int64)
     deltas = np.zeros(B, dtype=np.int64)
-    gi = 0
     for b in range(B):
         keep = mask[b].astype(bool)
         row = ids[b][keep]
         n = row.shape[0]
-        is_img = row == image_token_id
+        kind = (row == image_token_id).astype(np.int8)
+        if video_token_id is not None:
+            kind = kind + 2 * (row == video_token_id).astype(np.int8)
         out = np.empty((3, n), dtype=np.int64)
-        # run boundaries
-        change = np.flatnonzero(np.diff(is_img.astype(np.int8))) + 1
+        change = np.flatnonzero(np.diff(kind)) + 1
         starts = np.concatenate([[0], change])
         ends = np.concatenate([change, [n]])
         cur = 0
         for s, e in zip(starts, ends):
-            if not is_img[s]:
+            k = int(kind[s]) if n else 0
+            if k == 0:
                 L = e - s
                 out[:, s:e] = np.arange(L, dtype=np.int64) + cur
                 cur += L
                 continue
-            # a run of image pads may hold several back-to-back images only if no text separates them; the
-            # reference's prompts always put <|vision_end|> text between images, but handle the general case.
+            # HF consumes one grid row per run; a run that holds several back-to-back blocks (no text between them: the
+            # reference's prompts never do that) is walked block by block here.
             p = s
             while p < e:
-                if gi >= len(grids):
-                    raise ValueError("more image placeholder runs than image_grid_thw rows")
-                t, h, w = grids[gi]
-                gi += 1
+                if gi[k] >= len(grids[k]):
+                    raise ValueError("more visual placeholder runs than grid rows")
+                t, h, w = grids[k][gi[k]]
+                gi[k] += 1
                 lh, lw = h // merge, w // merge
                 cnt = t * lh * lw
                 if p + cnt > e:
                     raise ValueError("Image features and image tokens do not match")
-                tt = np.repeat(np.arange(t), lh * lw)
-                hh = np.tile(np.repeat(np.arange(lh), lw), t)
-                ww = np.tile(np.arange(lw), t * lh)
-                out[0, p:p + cnt] = tt + cur
-                out[1, p:p + cnt] = hh + cur
-                out[2, p:p + cnt] = ww + cur
-                cur += max(h, w) // merge
+                if k == 2 and not split_video_frames:
+                    sec = 1.0 if spg is None else spg[vi]
+                    vi += 1
+                    if mode == "tf5":
+                        tsteps = np.arange(t, dtype=np.int64) * (int(tokens_per_second) * int(sec))
+                    else:
+                        tsteps = (np.arange(t, dtype=np.float64) * sec * tokens_per_second).astype(np.int64)
+                else:
+                    tsteps = np.arange(t, dtype=np.int64)
+                out[0, p:p + cnt] = np.repeat(tsteps, lh * lw) + cur
+                out[1, p:p + cnt] = np.tile(np.repeat(np.arange(lh), lw), t) + cur
+                out[2, p:p + cnt] = np.tile(np.arange(lw), t * lh) + cur
+                if mode == "tf5":
+                    cur += max(h, w) // merge
+                else:
+                    cur = int(out[:, p:p + cnt].max()) + 1
                 p += cnt
         pos[:, b, keep] = out
         deltas[b] = (out.max() + 1 - n) if n else 0
-    if gi != len(grids):
+    if gi[1] != len(grids[1]) or gi[2] != len(grids[2]):
         raise ValueError("Image features and image tokens do not match")
     return pos, deltas
 
@@ -148,13 +178,22 @@ def decode_positions(attention_mask, deltas, n_new):
     return np.broadcast_to(p[None], (3,) + p.shape).copy()  # [3,B,n_new]
 
 
-def embed_source_rows(input_ids, image_token_id):
-    """row >= 0: embedding-table row; row < 0: -(k+1) for the k-th visual token (masked_scatter order)."""
+def embed_source_rows(input_ids, image_token_id, video_token_id=None, n_image_rows=None):
+    """row >= 0: embedding-table row; row < 0: -(k+1) for row k of the visual-token tensor (masked_scatter order, TF:1206-1215).
+    With video placeholders the visual tensor is [image tokens ; video tokens] (each modality scattered in its own order):
+    the j-th <|video_pad|> takes row n_image_rows + j.  Returns (src i32, n_image_tokens, n_video_tokens)."""
     ids = np.asarray(input_ids).reshape(-1).astype(np.int64)
     is_img = ids == image_token_id
+    n_img = int(is_img.sum())
     src = ids.copy()
-    src[is_img] = -(np.arange(int(is_img.sum()), dtype=np.int64) + 1)
-    return src.astype(np.int32), int(is_img.sum())
+    src[is_img] = -(np.arange(n_img, dtype=np.int64) + 1)
+    n_vid = 0
+    if video_token_id is not None:
+        is_vid = ids == video_token_id
+        n_vid = int(is_vid.sum())
+        base = n_img if n_image_rows is None else int(n_image_rows)
+        src[is_vid] = -(base + np.arange(n_vid, dtype=np.int64) + 1)
+    return src.astype(np.int32), n_img, n_vid
 
 
 def mrope_axis_table(mrope_section):
@@ -211,10 +250,12 @@ def pos_embed_taps(grid_thw, side, merge=2):
     return _pos_embed_taps_cached(_grid_key(grid_thw), int(side), int(merge))
 
 
-def deepstack_rows(input_ids, image_token_id, first=0):
-    """Rows of the visual tokens among the flattened prompt rows first.. and their ordinal among all visual tokens."""
+def deepstack_rows(input_ids, image_token_id, first=0, video_token_id=None):
+    """Rows of the visual tokens among the flattened prompt rows first.. and the row of the visual-token tensor
+    ([image tokens ; video tokens], as embed_source_rows) each one takes its DeepStack features from (TF3:1198-1218)."""
     ids = np.asarray(input_ids).reshape(-1)
-    at = np.flatnonzero(ids == image_token_id)
-    order = np.arange(at.shape[0])
+    src, _, _ = embed_source_rows(ids, image_token_id, video_token_id)
+    at = np.flatnonzero(src < 0)
+    order = -(src[at].astype(np.int64) + 1)
     keep = at >= first
     return (at[keep] - first).astype(np.int32), order[keep].astype(np.int32)

@@ -109,6 +109,10 @@ class GroupRollout:
         if self.max_prompt_length is not None:          # left truncation of ids only, as the reference (R:…:569-578)
             ids, mask = ids[:, -self.max_prompt_length:], mask[:, -self.max_prompt_length:]
         pv, grid = prompt_inputs.get("pixel_values"), prompt_inputs.get("image_grid_thw")
+        # the non-multi-image branch of the trainer hands the processor's native video tensors over (R:…:555-564); generate sees
+        # second_per_grid_ts, the log-prob passes do not (the trainer deletes it first, R:…:608-609)
+        vid = {k: prompt_inputs[k] for k in ("pixel_values_videos", "video_grid_thw") if prompt_inputs.get(k) is not None}
+        spg = prompt_inputs.get("second_per_grid_ts")
         from .hf_api import GenerationConfigLike
         rank, world = o3v_dist.world()
         sharded = self.group_parallel and world > 1
@@ -124,14 +128,14 @@ class GroupRollout:
                                   top_k=self.top_k, repetition_penalty=1.0, num_return_sequences=G_local,
                                   pad_token_id=self.pad, row_id_offset=rank * G_local if sharded else 0)
         pc = self.model.generate(input_ids=ids, attention_mask=mask, pixel_values=pv, image_grid_thw=grid,
-                                 generation_config=gc)
+                                 generation_config=gc, **vid, **({"second_per_grid_ts": spg} if vid and spg is not None else {}))
         S = ids.shape[1]
         comp = pc[:, S:]
         cmask = completion_mask(comp, self.eos)
         # per-token log-probs of the completions under the policy and the reference model (R:…:601-632): the G rows share
         # the prompt, so each model runs the ViT and the prompt once and the lm_head only over the G x T kept positions
-        lp = self._logps(self.model, ids, mask, comp, pv, grid, pc)
-        ref = lp if self.ref_model is None else self._logps(self.ref_model, ids, mask, comp, pv, grid, pc)
+        lp = self._logps(self.model, ids, mask, comp, pv, grid, pc, vid)
+        ref = lp if self.ref_model is None else self._logps(self.ref_model, ids, mask, comp, pv, grid, pc, vid)
         kl = per_token_kl(ref, lp)
         texts = self.decode(comp)
         completions = [[{"role": "assistant", "content": t}] for t in texts]
@@ -159,14 +163,15 @@ class GroupRollout:
         res.metrics = self.gather_metrics(res, std)
         return res
 
-    def _logps(self, model, ids, mask, comp, pv, grid, pc):
+    def _logps(self, model, ids, mask, comp, pv, grid, pc, vid=None):
+        vid = vid or {}
         if hasattr(model, "completion_logps"):
-            return model.completion_logps(ids, mask, comp, pv, grid)
+            return model.completion_logps(ids, mask, comp, pv, grid, **vid)
         # any other HF-style model: the reference's own formulation
         S = ids.shape[1]
         full_mask = torch.cat([torch.as_tensor(mask).to(pc.device).repeat_interleave(self.G, dim=0), torch.ones_like(comp)], dim=1)
         rep = lambda t: None if t is None else torch.as_tensor(t).repeat(pc.shape[0], *([1] * (torch.as_tensor(t).dim() - 1)))
-        return model.per_token_logps(pc, full_mask, rep(pv), rep(grid))[:, S - 1:]
+        return model.per_token_logps(pc, full_mask, rep(pv), rep(grid), **{k: rep(v) for k, v in vid.items()})[:, S - 1:]
 
     def gather_metrics(self, res: RolloutResult, std: torch.Tensor) -> Dict[str, float]:
         """One all_gather of [G, n_funcs+4] replaces six gather_for_metrics (R:…:711-738)."""

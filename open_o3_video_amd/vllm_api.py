@@ -9,6 +9,9 @@ R:eval/inference_example.py:15-29,75-82 and R:eval/models/model_vllm.py:18-33,10
 The engine tokenises `prompt` itself, expands each <|image_pad|> to gh*gw/4 placeholders
 (TF:models/qwen2_5_vl/processing_qwen2_5_vl.py:59-62) and runs the fused GPU frame pipeline on the images
 (list of PIL images, a [T,3,H,W] tensor / ndarray as process_vision_info returns it, or a single image).
+`multi_modal_data["video"]` (what QwenVL_VLLM.__call__ sends, R:eval/models/model_vllm.py:72-88,99-103: the [T,3,H,W] array of
+process_vision_info under a <|vision_start|><|video_pad|><|vision_end|> prompt) is the native video input: temporal patches of two
+frames, one <|video_pad|> expanded to T/2*gh*gw/4 placeholders, rope time advancing per temporal patch.
 temperature == 0 -> greedy; otherwise temperature / top-p sampling with repetition penalty over prompt + output.
 """
 from __future__ import annotations
@@ -60,12 +63,15 @@ def _load_tokenizer(path):
 
 class LLM:
     IMAGE_PAD = "<|image_pad|>"
+    VIDEO_PAD = "<|video_pad|>"
+    VISION_START, VISION_END = "<|vision_start|>", "<|vision_end|>"
 
     def __init__(self, model: str = None, tensor_parallel_size: int = 1, max_model_len: int = 81920,
                  gpu_memory_utilization: float = 0.9, limit_mm_per_prompt: Optional[dict] = None, dtype: str = "bfloat16",
                  max_num_seqs: int = 8, engine: Optional[O3VEngine] = None, tokenizer: Any = None,
                  min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda",
-                 enable_prefix_caching: bool = True, quantization: Optional[str] = None, **_):
+                 enable_prefix_caching: bool = True, quantization: Optional[str] = None, mm_processor_kwargs: Optional[dict] = None,
+                 position_mode: str = "pinned", **_):
         if tensor_parallel_size != 1:
             raise ValueError("the reference runs tensor_parallel_size=1 (R:eval/models/model_vllm.py:21); data parallelism "
                              "is one engine per GPU (open_o3_video_amd.dist)")
@@ -115,16 +121,18 @@ class LLM:
         # prompts over identical frames are prefilled; vLLM's `enable_prefix_caching` keyword switches it
         self.enable_prefix_caching = bool(enable_prefix_caching)
         self.prefix_tokens_reused = 0
+        # native video inputs: HF's Qwen2_5_VLProcessor gives every video second_per_grid_ts = temporal_patch_size / fps with
+        # fps = 2.0 unless mm_processor_kwargs={"fps": ...} says otherwise (TF:models/qwen2_5_vl/processing_qwen2_5_vl.py:143-153;
+        # the reference passes none, R:eval/models/model_vllm.py:18-26)
+        self.mm_processor_kwargs = dict(mm_processor_kwargs or {})
+        # video rope arithmetic: "pinned" = vllm 0.7.2's MRotaryEmbedding.get_input_positions (R:setup.sh:7; restated, parity
+        # unpinned), "tf5" = transformers 5.15 (goldens G5b / G14 / G15); see indexing.rope_index
+        self.position_mode = position_mode
 
     # ---- multimodal input -> uint8/f32 frames [T,3,H,W] with H,W multiples of 28
     def _frames(self, mm) -> Optional[torch.Tensor]:
         if not mm:
             return None
-        if mm.get("video", None) is not None:
-            # R:eval/models/model_vllm.py:92-126 sends frames under "image" (one <|image_pad|> per frame); a native "video"
-            # entry needs <|video_pad|> expansion and per-temporal-patch rope positions, which this engine does not build
-            raise NotImplementedError("multi_modal_data['video'] is not supported: pass the frames under 'image' with one "
-                                      "<|image_pad|> per frame, as eval/inference_example.py does")
         data = mm.get("image", None)
         if data is None:
             return None
@@ -156,33 +164,104 @@ class LLM:
             data = vp.resize_frames_device(data, (rh, rw))   # antialiased bicubic on the GPU; frames stay on the device
         return data
 
-    def _visual_tokens(self, frames: torch.Tensor) -> torch.Tensor:
-        """ViT + merger output for `frames`, cached by content: (shape, dtype, 128-bit hash of the bytes computed on the device
-        by o3v_content_hash128 -- one pass over the frames, one 16-byte read-back)."""
+    def _videos(self, mm):
+        """multi_modal_data["video"] -> list of (frames [T,3,H,W] sized by smart_resize, metadata dict).  One array / tensor is one
+        video (R:eval/models/model_vllm.py:72-88 sends `v_input.numpy()`, f32 0..255 from process_vision_info); a list holds
+        several; an (array, metadata) pair carries {"fps", "frames_indices"} for Qwen3-VL's timestamps."""
+        data = None if not mm else mm.get("video", None)
+        if data is None:
+            return []
+        if isinstance(data, tuple) and len(data) == 2 and isinstance(data[1], dict):
+            data = [data]
+        elif not isinstance(data, list):
+            data = [data]
+        lim = self.limit_mm.get("video")
+        if lim is not None and len(data) > lim:
+            raise ValueError(f"{len(data)} videos exceed limit_mm_per_prompt['video']={lim}")
+        out = []
+        for item in data:
+            meta = {}
+            if isinstance(item, tuple) and len(item) == 2 and isinstance(item[1], dict):
+                item, meta = item
+            v = item if torch.is_tensor(item) else torch.as_tensor(np.asarray(item))
+            if v.dim() != 4:
+                raise ValueError("a video is a [T,3,H,W] (or [T,H,W,3]) array of frames")
+            if v.shape[1] != 3 and v.shape[-1] == 3:
+                v = v.permute(0, 3, 1, 2)
+            T, _, H, W = v.shape
+            rh, rw = vp.smart_resize(H, W, self.image_factor, self.min_pixels, self.max_pixels)
+            if (rh, rw) != (H, W):
+                v = vp.resize_frames_device(v, (rh, rw))
+            out.append((v, dict(meta)))
+        return out
+
+    def _cached_visual(self, fr: torch.Tensor, video: bool):
+        """ViT + merger output for image frames / one native video, cached by content: (kind, shape, dtype, 128-bit hash of the
+        bytes computed on the device by o3v_content_hash128 -- one pass over the frames, one 16-byte read-back)."""
         import ctypes as C
         from . import _lib
-        fr = frames.to(self.engine.dev).contiguous()
+        fr = fr.to(self.engine.dev).contiguous()
         h = torch.zeros(2, dtype=torch.int64, device=fr.device)
         _lib.call("o3v_content_hash128", C.c_void_p(fr.data_ptr()), fr.numel() * fr.element_size(), C.c_void_p(h.data_ptr()),
                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        key = (tuple(fr.shape), str(fr.dtype)) + tuple(int(v) for v in h.tolist())
+        key = ("video" if video else "image", tuple(fr.shape), str(fr.dtype)) + tuple(int(v) for v in h.tolist())
         hit = self._vis_cache.get(key)
         if hit is not None:
             self.vis_cache_hits += 1
-            return hit, key
-        px, grid = self.engine.pixels_from_frames(fr)
+            return hit[0], hit[1], key
+        px, grid = self.engine.pixels_from_video(fr) if video else self.engine.pixels_from_frames(fr)
         vis = self.engine.vit_forward(px, grid)
         if len(self._vis_cache) >= self.vis_cache_size:
             self._vis_cache.pop(next(iter(self._vis_cache)))
-        self._vis_cache[key] = vis
+        self._vis_cache[key] = (vis, grid)
+        return vis, grid, key
+
+    def _visual_tokens(self, frames: torch.Tensor):
+        vis, _, key = self._cached_visual(frames, video=False)
         return vis, key
 
-    def _tokenize(self, prompt: str, n_frames: int, tok_per_frame: int):
+    def _video_placeholder(self, grid_row, meta) -> str:
+        """What one <|video_pad|> of the prompt becomes.  Qwen2.5-VL (TF:models/qwen2_5_vl/processing_qwen2_5_vl.py:64-67): t*gh*gw/4
+        pads.  Qwen3-VL (TF:models/qwen3_vl/processing_qwen3_vl.py:81-107,178-189): per temporal patch "<{t:.1f} seconds>" +
+        <|vision_start|> gh*gw/4 pads <|vision_end|>, the time being the mean of the patch's first / last frame index over the
+        video fps (fps 24 and indices 0..T-1 when the request carries no metadata, as HF falls back)."""
+        t, gh, gw = (int(v) for v in grid_row)
+        per = gh * gw // self.cfg.vision.merge_unit
+        if self.cfg.arch != "qwen3_vl":
+            return self.VIDEO_PAD * (t * per)
+        fps = float(meta.get("fps") or 24)
+        idx = list(meta.get("frames_indices") if meta.get("frames_indices") is not None else range(int(meta.get("n_frames", 2 * t))))
+        idx = [float(i) for i in idx]
+        if len(idx) % 2:
+            idx.append(idx[-1])
+        ts = [i / fps for i in idx]
+        ts = [(ts[i] + ts[i + 1]) / 2 for i in range(0, len(ts), 2)]
+        return "".join(f"<{ts[k]:.1f} seconds>" + self.VISION_START + self.VIDEO_PAD * per + self.VISION_END for k in range(t))
+
+    def _tokenize(self, prompt: str, n_frames: int, tok_per_frame: int, video_placeholders: Sequence[str] = ()):
         if n_frames:
             n_tags = prompt.count(self.IMAGE_PAD)
             if n_tags != n_frames:
                 raise ValueError(f"prompt has {n_tags} image placeholders but {n_frames} images were given")
             prompt = prompt.replace(self.IMAGE_PAD, self.IMAGE_PAD * tok_per_frame)
+        n_vtags = prompt.count(self.VIDEO_PAD)
+        if n_vtags != len(video_placeholders):
+            raise ValueError(f"prompt has {n_vtags} video placeholders but {len(video_placeholders)} videos were given")
+        if n_vtags:
+            q3 = self.cfg.arch == "qwen3_vl"
+            triple = self.VISION_START + self.VIDEO_PAD + self.VISION_END
+            parts, rest = [], prompt
+            for ph in video_placeholders:
+                i = rest.index(self.VIDEO_PAD)
+                # Qwen3-VL's expansion carries its own <|vision_start|> / <|vision_end|> per temporal patch: it replaces the whole
+                # <|vision_start|><|video_pad|><|vision_end|> of the chat template when the pad stands inside one
+                if q3 and rest[max(0, i - len(self.VISION_START)):i + len(self.VIDEO_PAD) + len(self.VISION_END)] == triple:
+                    parts.append(rest[:i - len(self.VISION_START)] + ph)
+                    rest = rest[i + len(self.VIDEO_PAD) + len(self.VISION_END):]
+                else:
+                    parts.append(rest[:i] + ph)
+                    rest = rest[i + len(self.VIDEO_PAD):]
+            prompt = "".join(parts) + rest
         ids = self.tokenizer.encode(prompt, add_special_tokens=False) if hasattr(self.tokenizer, "encode") else self.tokenizer(prompt)
         return list(ids)
 
@@ -200,18 +279,42 @@ class LLM:
                       temperature=1.0 if greedy else sp.temperature, top_p=1.0 if greedy else sp.top_p, return_margins=False)
         # ---- per request: frames -> (cached) visual tokens, prompt -> ids
         prepared = []
+        tps = self.cfg.vision.temporal_patch_size
+        fps = float(self.mm_processor_kwargs.get("fps", 2.0))
+        self.engine.position_mode = self.position_mode
         for req in inputs:
             prompt = req["prompt"] if isinstance(req, dict) else str(req)
-            frames = self._frames(req.get("multi_modal_data") if isinstance(req, dict) else None)
+            mm = req.get("multi_modal_data") if isinstance(req, dict) else None
+            frames = self._frames(mm)
+            videos = self._videos(mm)
             tpf = 0 if frames is None else (frames.shape[2] // self.image_factor) * (frames.shape[3] // self.image_factor)
-            ids = self._tokenize(prompt, 0 if frames is None else frames.shape[0], tpf)
+            vis_i, grid, keys = None, None, []
+            if frames is not None:
+                vis_i, k = self._visual_tokens(frames)
+                keys.append(k)
+                ps = self.cfg.vision.patch_size
+                grid = np.asarray([[1, frames.shape[2] // ps, frames.shape[3] // ps]] * frames.shape[0], dtype=np.int64)
+            vis_v, vgrids, placeholders = [], [], []
+            for v, meta in videos:
+                vv, vg, k = self._cached_visual(v, video=True)
+                vis_v.append(vv)
+                vgrids.append(vg)
+                placeholders.append(self._video_placeholder(vg[0], dict(meta, n_frames=v.shape[0])))
+                keys.append(k)
+            ids = self._tokenize(prompt, 0 if frames is None else frames.shape[0], tpf, placeholders)
             if len(ids) + sp.max_tokens > self.max_model_len:
                 raise ValueError(f"prompt ({len(ids)}) + max_tokens ({sp.max_tokens}) exceeds max_model_len {self.max_model_len}")
-            vis, grid, vkey = None, None, ("text-only",)
-            if frames is not None:
-                vis, vkey = self._visual_tokens(frames)
-                grid = np.asarray([[1, frames.shape[2] // 14, frames.shape[3] // 14]] * frames.shape[0], dtype=np.int64)
-            prepared.append((prompt, ids, vis, grid, vkey))
+            vkey = tuple(keys) if keys else ("text-only",)      # identifies the visual content of the prompt (prefix-K/V reuse)
+            vgrid = np.concatenate(vgrids) if vgrids else None
+            spg = [tps / fps] * len(vgrids) if vgrids else None
+            prepared.append((prompt, ids, vis_i, grid, vkey, vis_v, vgrid, spg))
+
+        def cat_visual(img_parts, vid_parts):
+            """[image tokens of every row ; video tokens of every row] -- the order engine.embed scatters them in."""
+            parts = [p for p in img_parts if p is not None] + [p for p in vid_parts if p is not None]
+            if not parts:
+                return None
+            return parts[0] if len(parts) == 1 else torch.cat(parts, dim=-2)
 
         def finish(ro, index, row, n_prompt):
             toks = row[n_prompt:].tolist()
@@ -233,10 +336,13 @@ class LLM:
                 pad = self.cfg.pad_token_id
                 rows = [[pad] * (L - len(p[1])) + p[1] for p in chunk]
                 mask = [[0] * (L - len(p[1])) + [1] * len(p[1]) for p in chunk]
-                vis_parts = [p[2] for p in chunk if p[2] is not None]
                 grid_parts = [p[3] for p in chunk if p[3] is not None]
-                out = self.engine.generate(rows, mask, vis_embeds=torch.cat(vis_parts) if vis_parts else None,
+                vgrid_parts = [p[6] for p in chunk if p[6] is not None]
+                spg_all = [x for p in chunk if p[7] for x in p[7]]
+                out = self.engine.generate(rows, mask, vis_embeds=cat_visual([p[2] for p in chunk], [v for p in chunk for v in p[5]]),
                                            image_grid_thw=np.concatenate(grid_parts) if grid_parts else None,
+                                           video_grid_thw=np.concatenate(vgrid_parts) if vgrid_parts else None,
+                                           second_per_grid_ts=spg_all or None,
                                            row_ids=[self._req + i for i in range(len(chunk))],
                                            seed=0 if sp.seed is None else sp.seed, **common)
                 for i, p in enumerate(chunk):
@@ -245,13 +351,15 @@ class LLM:
                     results.append(ro)
                     self._req += 1
             return results
-        for prompt, ids, vis, grid, vkey in prepared:
+        for prompt, ids, vis_i, grid, vkey, vis_v, vgrid, spg in prepared:
+            vis = cat_visual([vis_i], vis_v)
             ro = RequestOutput(request_id=str(self._req), prompt=prompt, prompt_token_ids=ids)
             # n samples of one prompt (self-consistency, R:eval/tts.py:47-123) run in groups of <= 16 decode rows; sample i is
             # keyed by (seed, i) whatever group it lands in, and groups after the first reuse the whole prompt K/V
             for i0 in range(0, sp.n, O3VEngine.MAX_ROWS):
                 g = min(O3VEngine.MAX_ROWS, sp.n - i0)
-                out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, num_return_sequences=g,
+                out = self.engine.generate([ids], None, vis_embeds=vis, image_grid_thw=grid, video_grid_thw=vgrid,
+                                           second_per_grid_ts=spg, num_return_sequences=g,
                                            row_ids=list(range(i0, i0 + g)), seed=self._req if sp.seed is None else sp.seed,
                                            prefix_key=vkey if self.enable_prefix_caching else None, **common)
                 self.prefix_tokens_reused += int(out.timings.get("prefix_tokens_reused", 0))

@@ -78,7 +78,7 @@ def test_tiles():
 
 
 def test_embed_source_rows():
-    src, n = indexing.embed_source_rows([[5, 500, 500, 7], [500, 1, 2, 500]], 500)
+    src, n, _ = indexing.embed_source_rows([[5, 500, 500, 7], [500, 1, 2, 500]], 500)
     assert n == 4 and src.tolist() == [5, -1, -2, 7, -3, 1, 2, -4]
 
 
@@ -122,7 +122,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/o3v.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.load().o3v_abi_version() == 5
+    assert _lib.load().o3v_abi_version() == 6
 
 
 def test_c_abi_argument_errors_without_gpu():
@@ -399,3 +399,93 @@ def test_fp8_quantiser_and_fragment_packing():
     p8 = pack_mfma_fragments_fp8(bi).view(2, 2, 64, 16)
     for nb, t, l in ((0, 0, 0), (1, 1, 37), (0, 1, 63)):
         assert torch.equal(p8[nb, t, l], bi[nb * 16 + (l & 15), t * 64 + (l >> 4) * 16: t * 64 + (l >> 4) * 16 + 16])
+
+
+# ------------------------------------------------------------------------------------------------ native video inputs
+def test_rope_index_video_matches_hf(golden_dir):
+    """indexing.rope_index(mode="tf5") == get_rope_index of transformers 5.15 on native video groups (golden G5b: Qwen2.5-VL with
+    second_per_grid_ts, several videos, video + image, left padding; Qwen3-VL's per-frame split)."""
+    import fixture_models_q3 as fq
+    g = np.load(os.path.join(golden_dir, "g5b_rope_index_video.npz"))
+    tps = int(g["tokens_per_second"][0])
+    tags = sorted({k[:-4] for k in g.files if k.endswith("_ids")})
+    for t in tags:
+        q3 = t.startswith("q3_")
+        cfg = fq.tiny_q3_config() if q3 else fm.tiny_config()
+        spg = list(g[f"{t}_spg"]) if bool(g[f"{t}_has_spg"][0]) and not q3 else None
+        pos, delta = indexing.rope_index(g[f"{t}_ids"], g[f"{t}_mask"], g[f"{t}_igrid"] if len(g[f"{t}_igrid"]) else None,
+                                         cfg["image_token_id"], video_grid_thw=g[f"{t}_vgrid"], video_token_id=cfg["video_token_id"],
+                                         second_per_grid_ts=spg, tokens_per_second=tps, split_video_frames=q3, mode="tf5")
+        assert np.array_equal(pos, g[f"{t}_pos"]), t
+        assert np.array_equal(delta, g[f"{t}_delta"].reshape(-1)), t
+
+
+def test_rope_index_video_pinned_mode():
+    """mode="pinned" (transformers @336dc69d / vllm 0.7.2, restated -- parity unpinned): the worked example of that release's
+    get_rope_index docstring (3 temporal patches of 2x2 merged tokens, fps 1 -> second_per_grid_t 2.0, tokens_per_second 25:
+    temporal ids 0,50,100, text continues at 101), fractional seconds are truncated AFTER the product, and the mode equals "tf5"
+    whenever the temporal extent stays inside the spatial one (and always for images)."""
+    V, I = 501, 500
+    ids = [[V] * 12 + [7, 8, 9, 10, 11]]
+    pos, delta = indexing.rope_index(ids, None, None, I, video_grid_thw=[[3, 4, 4]], video_token_id=V, second_per_grid_ts=[2.0],
+                                     tokens_per_second=25, mode="pinned")
+    assert pos[0, 0, :12].tolist() == [0] * 4 + [50] * 4 + [100] * 4
+    assert pos[1, 0, :12].tolist() == [0, 0, 1, 1] * 3 and pos[2, 0, :12].tolist() == [0, 1, 0, 1] * 3
+    assert pos[:, 0, 12:].tolist() == [[101, 102, 103, 104, 105]] * 3 and int(delta[0]) == 106 - 17
+    # 0.5 s per temporal patch at 2 tokens/s: 0, 1, 2, 3 (tf5 truncates the seconds first: all 0)
+    p, _ = indexing.rope_index([[V] * 4 + [9]], None, None, I, video_grid_thw=[[4, 2, 2]], video_token_id=V, second_per_grid_ts=[0.5],
+                               tokens_per_second=2, mode="pinned")
+    assert p[0, 0].tolist() == [0, 1, 2, 3, 4]
+    q, _ = indexing.rope_index([[V] * 4 + [9]], None, None, I, video_grid_thw=[[4, 2, 2]], video_token_id=V, second_per_grid_ts=[0.5],
+                               tokens_per_second=2, mode="tf5")
+    assert q[0, 0].tolist() == [0, 0, 0, 0, 1]
+    # images, and a video whose temporal extent is below its width: both modes agree
+    cfg = fm.tiny_config()
+    idm = fm.make_prompt_mm(cfg, [("image", (1, 4, 6)), ("video", (2, 4, 12)), ("image", (1, 8, 4))], seed=3)
+    kw = dict(video_grid_thw=[[2, 4, 12]], video_token_id=cfg["video_token_id"], second_per_grid_ts=[1.0], tokens_per_second=2)
+    a = indexing.rope_index([idm], None, [[1, 4, 6], [1, 8, 4]], cfg["image_token_id"], mode="tf5", **kw)
+    b = indexing.rope_index([idm], None, [[1, 4, 6], [1, 8, 4]], cfg["image_token_id"], mode="pinned", **kw)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        indexing.rope_index([idm], None, [[1, 4, 6], [1, 8, 4]], cfg["image_token_id"], mode="x", **kw)
+    with pytest.raises(ValueError):       # a video placeholder run without its grid row
+        indexing.rope_index([idm], None, [[1, 4, 6], [1, 8, 4]], cfg["image_token_id"], video_token_id=cfg["video_token_id"])
+
+
+def test_embed_source_rows_with_video():
+    """Image placeholders take the first rows of the visual tensor, video placeholders the rows after ALL image rows, whatever
+    their order in the prompt (each modality is scattered on its own, TF:1206-1215); DeepStack rows follow the same map."""
+    src, ni, nv = indexing.embed_source_rows([[5, 501, 501, 500, 7, 500, 501]], 500, 501)
+    assert (ni, nv) == (2, 3) and src.tolist() == [5, -3, -4, -1, 7, -2, -5]
+    rows, order = indexing.deepstack_rows([[5, 501, 501, 500, 7, 500, 501]], 500, video_token_id=501)
+    assert rows.tolist() == [1, 2, 3, 5, 6] and order.tolist() == [2, 3, 0, 1, 4]
+    rows, order = indexing.deepstack_rows([[5, 501, 501, 500, 7, 500, 501]], 500, first=3, video_token_id=501)
+    assert rows.tolist() == [0, 2, 3] and order.tolist() == [0, 1, 4]
+    src, ni, nv = indexing.embed_source_rows([[5, 500, 501]], 500)          # no video id given: 501 stays a text row
+    assert (ni, nv) == (1, 0) and src.tolist() == [5, -1, 501]
+
+
+def test_vllm_video_placeholder_expansion():
+    """One <|video_pad|> per video in the prompt (R:eval/models/model_vllm.py:41-60 via the chat template).  Qwen2.5-VL: t*gh*gw/4
+    pads in place; Qwen3-VL: a "<ts seconds><|vision_start|>pads<|vision_end|>" block per temporal patch replacing the template's
+    whole <|vision_start|><|video_pad|><|vision_end|> (TF:models/qwen3_vl/processing_qwen3_vl.py:81-107,178-189)."""
+    import types
+    from open_o3_video_amd.vllm_api import LLM
+    llm = LLM.__new__(LLM)
+    llm.cfg = types.SimpleNamespace(arch="qwen2_5_vl", vision=types.SimpleNamespace(merge_unit=4))
+    llm.tokenizer = types.SimpleNamespace(encode=lambda text, add_special_tokens=False: text)
+    ph = llm._video_placeholder((3, 4, 6), {})
+    assert ph == "<|video_pad|>" * 18
+    out = llm._tokenize("a<|vision_start|><|video_pad|><|vision_end|>b<|image_pad|>c", 1, 2, [ph])
+    assert "".join(out) == "a<|vision_start|>" + "<|video_pad|>" * 18 + "<|vision_end|>b<|image_pad|><|image_pad|>c"
+    with pytest.raises(ValueError):
+        llm._tokenize("a<|video_pad|>b", 0, 0, [])
+    with pytest.raises(ValueError):
+        llm._tokenize("ab", 0, 0, [ph])
+    llm.cfg = types.SimpleNamespace(arch="qwen3_vl", vision=types.SimpleNamespace(merge_unit=4))
+    ph3 = llm._video_placeholder((2, 4, 4), {"fps": 2.0, "frames_indices": [0, 4, 8]})       # odd count: last index repeated
+    blk = lambda ts: f"<{ts} seconds><|vision_start|>" + "<|video_pad|>" * 4 + "<|vision_end|>"
+    assert ph3 == blk("1.0") + blk("4.0")
+    out = llm._tokenize("a<|vision_start|><|video_pad|><|vision_end|>b", 0, 0, [ph3])
+    assert "".join(out) == "a" + ph3 + "b"
+    assert llm._video_placeholder((2, 4, 4), {"n_frames": 4}) == blk("0.0") + blk("0.1")      # no metadata: fps 24, indices 0..3
