@@ -189,3 +189,42 @@ def test_group_parallel_rollout_equals_single_rank_group():
             gr.step({"input_ids": torch.tensor([[1]]), "attention_mask": torch.ones(1, 1, dtype=torch.int64)}, {})
         finally:
             od.world = orig
+
+
+def test_gspo_against_the_reference_lines(golden_dir):
+    """Golden G10b: the trainer's OWN statements (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:591-596, :635-636, :675-681, :691-706,
+    :711-738) executed from the reference source by tools/make_golden.py g10b with a stub `self` on fixed inputs -- EOS mask, clamped
+    k3 KL, group advantages (unbiased std + 1e-4), sequence-level (GSPO) and token-level clipped objectives with ratio != 1, beta 0,
+    equal rewards, rows without EOS -- against rollout.py (the product) and oracle/gspo_ref.py (the transcription)."""
+    import numpy as np
+    import os
+    g = np.load(os.path.join(golden_dir, "g10b_gspo.npz"))
+    n = len({k.split("_")[0] for k in g.files})
+    assert n == 6
+    for i in range(n):
+        k = f"c{i}_"
+        G, B, T, eos = (int(v) for v in g[k + "params"])
+        beta, el, eh, gspo = (float(v) for v in g[k + "hyper"])
+        gspo = bool(gspo)
+        cids = torch.from_numpy(g[k + "completion_ids"])
+        lp, old, ref = (torch.from_numpy(g[k + n_]) for n_ in ("logps", "old_logps", "ref_logps"))
+        rewards = torch.from_numpy(g[k + "rewards"])
+        mask = rollout.completion_mask(cids, eos)
+        assert torch.equal(mask, torch.from_numpy(g[k + "completion_mask"])) and torch.equal(gspo_ref.eos_mask(cids, eos), mask)
+        kl = rollout.per_token_kl(ref, lp)
+        assert torch.equal(kl, torch.from_numpy(g[k + "per_token_kl"]))
+        adv, std = rollout.group_advantages(rewards, G)
+        assert torch.equal(adv, torch.from_numpy(g[k + "advantages"])) and torch.equal(std, torch.from_numpy(g[k + "std"]))
+        loss = rollout.gspo_loss(lp, old, ref, adv, mask, beta, el, eh, gspo)
+        assert abs(float(loss) - float(g[k + "loss"])) <= 1e-6 * max(1.0, abs(float(g[k + "loss"]))), (i, float(loss), float(g[k + "loss"]))
+        lo, ao, ko, so = gspo_ref.loss_and_parts(lp, ref, rewards, mask, G, beta, el, eh, gspo, old_logps=old)
+        assert float(lo) == float(loss) or abs(float(lo) - float(g[k + "loss"])) <= 1e-6 * max(1.0, abs(float(lo)))
+        assert torch.equal(ao, adv) and torch.equal(ko, kl)
+        # the logging record (R:…:711-738) from the product's gather on one rank
+        gr = rollout.GroupRollout(None, [], None, eos, 0, num_generations=G)
+        res = rollout.RolloutResult(None, cids, mask, lp, ref, kl, rewards[:, None], rewards, adv, loss, [])
+        gr.reward_funcs = []
+        m = gr.gather_metrics(res, std)
+        want = dict(zip(("completion_length", "all_wrong", "all_correct", "reward", "reward_std", "kl"), g[k + "metrics"]))
+        for name, v in want.items():
+            assert abs(m[name] - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (i, name, m[name], float(v))

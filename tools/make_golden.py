@@ -828,5 +828,87 @@ def g9_rewards_spans():
     print("G9 written:", len(out["cases"]), "task cases x", n, "completions")
 
 
+# ------------------------------------------------------------------------------------------------ G10b GSPO math
+def _exec_reference_lines(path, first, last, starts_with, ns):
+    """Execute lines first..last (1-based, inclusive) of a reference source file in namespace `ns` -- the method-body slices of
+    a module that cannot be imported here (trl absent).  `starts_with` guards against the file having moved under the numbers."""
+    import textwrap
+    lines = open(path).read().split("\n")[first - 1:last]
+    assert lines[0].strip().startswith(starts_with), (first, lines[0])
+    exec(compile(textwrap.dedent("\n".join(lines)), f"{path}:{first}-{last}", "exec"), ns)
+    return ns
+
+
+class _LogpsWithOld(torch.Tensor):
+    """per_token_logps whose .detach() returns the OLD policy's values, so that the reference's `per_token_logps -
+    per_token_logps.detach()` (R:grpo_trainer.py:691) is evaluated for a ratio != 1 as in the optimisation steps after the first."""
+    @staticmethod
+    def make(new, old):
+        t = torch.Tensor._make_subclass(_LogpsWithOld, new.clone())
+        t._old = old
+        return t
+
+    def detach(self):
+        return self._old
+
+
+def g10b_gspo():
+    """The trainer's own lines (R:src/r1-v/src/open_r1/trainer/grpo_trainer.py:591-596 EOS mask, :635-636 KL, :675-681 advantages,
+    :691-706 GSPO / GRPO objective, :711-738 metrics) executed from the reference source on fixed inputs with a stub `self`."""
+    path = "/root/reference/src/r1-v/src/open_r1/trainer/grpo_trainer.py"
+    res = {}
+    cases = [dict(G=4, B=1, T=12, beta=0.04, el=0.2, eh=0.2, gspo=True, seed=0, old_scale=0.0),
+             dict(G=4, B=1, T=12, beta=0.04, el=0.2, eh=0.2, gspo=False, seed=1, old_scale=0.3),
+             dict(G=8, B=2, T=20, beta=0.04, el=0.2, eh=0.2, gspo=True, seed=2, old_scale=0.5),
+             dict(G=8, B=1, T=16, beta=0.1, el=0.1, eh=0.3, gspo=True, seed=3, old_scale=1.5),
+             dict(G=2, B=3, T=5, beta=0.0, el=0.2, eh=0.2, gspo=False, seed=4, old_scale=2.0),
+             dict(G=4, B=1, T=6, beta=0.04, el=0.2, eh=0.2, gspo=True, seed=5, old_scale=0.2, equal_rewards=True)]
+    for ci, c in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + c["seed"])
+        N, T = c["B"] * c["G"], c["T"]
+        eos_id = 7
+        completion_ids = torch.randint(8, 50, (N, T), generator=g)
+        for r in range(N):                                   # some rows end early, one row has no EOS, one starts with it
+            if r % 3 != 2:
+                completion_ids[r, int(torch.randint(0, T, (1,), generator=g))] = eos_id
+        logps = -torch.rand(N, T, generator=g) * 3
+        old = logps + c["old_scale"] * 0.2 * torch.randn(N, T, generator=g)
+        ref = logps + 0.5 * torch.randn(N, T, generator=g)
+        ref[0, 0] = logps[0, 0] + 25.0                       # exercises the clamp at +-10
+        ref[-1, -1] = logps[-1, -1] - 25.0
+        rewards = torch.full((N,), 1.5) if c.get("equal_rewards") else torch.rand(N, generator=g) * 3
+        me = types.SimpleNamespace(
+            processing_class=types.SimpleNamespace(eos_token_id=eos_id), accelerator=types.SimpleNamespace(
+                device=torch.device("cpu"), gather_for_metrics=lambda t: t), num_generations=c["G"], beta=c["beta"],
+            epsilon_low=c["el"], epsilon_high=c["eh"], gspo=c["gspo"], reward_funcs=[], _metrics={k: [] for k in (
+                "completion_length", "all_wrong", "all_correct", "reward", "reward_std", "kl")})
+        ns = {"torch": torch, "self": me, "completion_ids": completion_ids, "PreTrainedModel": type(None)}
+        _exec_reference_lines(path, 591, 596, "is_eos = completion_ids ==", ns)
+        ns["per_token_logps"] = _LogpsWithOld.make(logps, old)
+        ns["ref_per_token_logps"] = ref
+        _exec_reference_lines(path, 635, 636, "x_clamped = torch.clamp", ns)
+        ns["rewards"] = rewards
+        ns["rewards_per_func"] = rewards[:, None]
+        _exec_reference_lines(path, 675, 681, "mean_grouped_rewards = rewards.view", ns)
+        _exec_reference_lines(path, 691, 706, "log_ratio = per_token_logps - per_token_logps.detach()", ns)
+        _exec_reference_lines(path, 711, 738, "completion_length = self.accelerator.gather_for_metrics", ns)
+        k = f"c{ci}_"
+        res.update({k + "params": np.asarray([c["G"], c["B"], T, eos_id], dtype=np.int64),
+                    k + "hyper": np.asarray([c["beta"], c["el"], c["eh"], float(c["gspo"])], dtype=np.float64),
+                    k + "completion_ids": completion_ids.numpy(), k + "logps": logps.numpy(), k + "old_logps": old.numpy(),
+                    k + "ref_logps": ref.numpy(), k + "rewards": rewards.numpy(),
+                    k + "completion_mask": ns["completion_mask"].numpy(), k + "per_token_kl": torch.Tensor(ns["per_token_kl"]).numpy(),
+                    k + "advantages": ns["advantages"].numpy(), k + "std": ns["std_grouped_rewards"].numpy(),
+                    k + "loss": np.asarray(float(ns["loss"]), dtype=np.float64),
+                    k + "metrics": np.asarray([me._metrics[m][0] for m in ("completion_length", "all_wrong", "all_correct", "reward",
+                                                                           "reward_std", "kl")], dtype=np.float64)})
+    np.savez_compressed(os.path.join(GOLD, "g10b_gspo.npz"), **res)
+    print("G10b written:", len(cases), "cases; losses", [float(res[f"c{i}_loss"]) for i in range(len(cases))])
+
+
+if __name__ == "__main__" and "g10b" in sys.argv[1:]:
+    g10b_gspo()
+
+
 if __name__ == "__main__" and "g9" in sys.argv[1:]:
     g9_rewards_spans()
