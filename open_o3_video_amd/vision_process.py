@@ -40,6 +40,36 @@ FPS_MAX_FRAMES = 16
 VIDEO_TOTAL_PIXELS = int(float(os.environ.get("VIDEO_MAX_PIXELS", 128000 * 28 * 28 * 0.9)))
 FORCE_QWENVL_VIDEO_READER = os.getenv("FORCE_QWENVL_VIDEO_READER", None)
 
+# Two sets of limits exist around the reference.  "vendored" (default; the values above) is the copy of qwen_vl_utils the
+# TRAINER imports (R:src/r1-v/src/open_r1/vision_process.py:25-42, pinned by golden G1).  "upstream" is the pip package
+# `qwen_vl_utils` that the EVAL scripts import instead (R:eval/inference_example.py:5, R:eval/models/model_vllm.py:3; unpinned in
+# R:setup.sh:5): its published constants allow far larger frames (a 640x360 video stays 364x644 instead of 224x420) and up to
+# 768 sampled frames.  The package is not installed offline, so the "upstream" values are a restatement of its published
+# vision_process.py (0.0.10 / 0.0.11): parity unpinned.  Eval users select it with set_profile("upstream").
+PROFILES = {
+    "vendored": dict(MIN_PIXELS=4 * 28 * 28, MAX_PIXELS=256 * 28 * 28, VIDEO_MIN_PIXELS=128 * 28 * 28,
+                     VIDEO_MAX_PIXELS=128 * 28 * 28, FPS_MIN_FRAMES=4, FPS_MAX_FRAMES=16),
+    "upstream": dict(MIN_PIXELS=4 * 28 * 28, MAX_PIXELS=16384 * 28 * 28, VIDEO_MIN_PIXELS=128 * 28 * 28,
+                     VIDEO_MAX_PIXELS=768 * 28 * 28, FPS_MIN_FRAMES=4, FPS_MAX_FRAMES=768),
+}
+_profile = "vendored"
+
+
+def set_profile(name: str) -> str:
+    """Switch the module's limits (MIN/MAX_PIXELS, VIDEO_MIN/MAX_PIXELS, FPS_MIN/MAX_FRAMES) to `name`; returns the previous
+    profile's name.  Every function of this module reads them at call time."""
+    global _profile
+    if name not in PROFILES:
+        raise ValueError(f"profile {name!r}: one of {sorted(PROFILES)}")
+    prev = _profile
+    globals().update(PROFILES[name])
+    _profile = name
+    return prev
+
+
+def get_profile() -> str:
+    return _profile
+
 
 def round_by_factor(number, factor):
     return round(number / factor) * factor
@@ -53,8 +83,11 @@ def floor_by_factor(number, factor):
     return math.floor(number / factor) * factor
 
 
-def smart_resize(height, width, factor=IMAGE_FACTOR, min_pixels=MIN_PIXELS, max_pixels=MAX_PIXELS):
-    """(H, W) divisible by `factor`, area within [min_pixels, max_pixels], aspect ratio kept as closely as possible."""
+def smart_resize(height, width, factor=IMAGE_FACTOR, min_pixels=None, max_pixels=None):
+    """(H, W) divisible by `factor`, area within [min_pixels, max_pixels], aspect ratio kept as closely as possible.
+    min_pixels / max_pixels default to the active profile's MIN_PIXELS / MAX_PIXELS."""
+    min_pixels = MIN_PIXELS if min_pixels is None else min_pixels
+    max_pixels = MAX_PIXELS if max_pixels is None else max_pixels
     ratio = max(height, width) / min(height, width)
     if ratio > MAX_RATIO:
         raise ValueError(f"absolute aspect ratio must be smaller than {MAX_RATIO}, got {ratio}")

@@ -145,3 +145,29 @@ def test_key_frame_interleave_matches_trainer_loop():
                 assert f[0, 0, 0].item() == idx + 1 and f[0].min().item() == idx + 1
     out, text = vp.interleave_key_frames(video, 2.0, [], prompt="a " + vp.VIDEO_TAG + " b")
     assert torch.equal(out, video) and text == "a " + vp.frames_as_images_prompt(vp.VIDEO_TAG, 6, 2.0) + " b"
+
+
+def test_upstream_profile():
+    """set_profile("upstream"): the limits of the pip `qwen_vl_utils` the eval scripts import (R:eval/inference_example.py:5,
+    R:eval/models/model_vllm.py:3) instead of the vendored copy's -- restated from the package's published constants, parity unpinned.
+    The canonical 640x360 eval video keeps 364x644 (SURVEY section 8 EVAL-RES) instead of the trainer's 224x420, and fps sampling may take
+    more than 16 frames; the vendored profile (golden G1) is untouched after switching back."""
+    from open_o3_video_amd import vision_process as vp
+    assert vp.get_profile() == "vendored"
+    base = (vp.smart_resize(360, 640), vp.video_pixel_budget(32, {}), vp.smart_nframes({}, 491, 22.29))
+    assert base[0] == (336, 588) and vp.smart_resize(360, 640, 28, *vp.video_pixel_budget(32, {})) == (224, 420) and base[2] == 16
+    prev = vp.set_profile("upstream")
+    try:
+        assert prev == "vendored" and vp.get_profile() == "upstream"
+        assert vp.MAX_PIXELS == 16384 * 784 and vp.VIDEO_MAX_PIXELS == 768 * 784 and vp.FPS_MAX_FRAMES == 768
+        assert vp.smart_resize(360, 640) == (364, 644)
+        assert vp.smart_resize(360, 640, 28, *vp.video_pixel_budget(32, {})) == (364, 644)
+        assert vp.smart_nframes({}, 491, 22.29) == 44                      # 22 s at 2 fps, no longer capped at 16
+        assert vp.smart_nframes({"nframes": 32}, 491, 22.29) == 32
+        # the reference's wrapper passes max_pixels per video (R:eval/models/model_vllm.py:14,45): it still bounds the frame
+        assert vp.smart_resize(360, 640, 28, *vp.video_pixel_budget(16, {"max_pixels": 360 * 420})) == (280, 504)
+        with pytest.raises(ValueError):
+            vp.set_profile("nope")
+    finally:
+        vp.set_profile("vendored")
+    assert (vp.smart_resize(360, 640), vp.video_pixel_budget(32, {}), vp.smart_nframes({}, 491, 22.29)) == base
