@@ -410,8 +410,12 @@ def main():
     # extra (not `value`): throughput with 16 videos decoding together per GPU -- the eval path of the reference runs a
     # vLLM engine with max_num_seqs=5 (R:eval/models/model_vllm.py:23), i.e. it batches concurrent requests too.  Decode is
     # weight-bandwidth-bound, so the 16 sequences share every streamed weight byte (MFMA skinny-GEMM path).
+    # The rank-0-only extras below (batched videos, fp8 rows, the CPU baseline) run only at N = 1: under
+    # --gpus N the other ranks would sit in the final barrier for tens of seconds while rank 0 measures them.
+    world_n = dist.get_world_size() if dist else 1
+    solo = world_n == 1
     batched = None
-    if not args.no_batched and rank == 0:
+    if not args.no_batched and rank == 0 and solo:
         NB = O3VEngine.MAX_ROWS
         vids8 = torch.randint(0, 256, (NB * args.frames, 3, Hres, Wres), generator=gen, dtype=torch.uint8, device=dev)
 
@@ -427,7 +431,7 @@ def main():
         assert o8.sequences.shape == (NB, S + args.new_tokens)
         batched = {"videos_per_step": NB, "tokens_per_s_per_gpu": round(NB * args.new_tokens / tb, 1),
                    "videos_per_min_per_gpu": round(NB / tb * 60.0, 1), "ms_per_step": round(tb * 1e3, 1)}
-    roof = None if (args.no_roofline or rank != 0) else kernel_roofline(eng)
+    roof = None if (args.no_roofline or rank != 0) else kernel_roofline(eng)   # a fraction of a second: kept at every N
     fused_flag = eng.fused_decode
     wbytes = sum(eng.w.t[f"l{l}.{k}"].numel() * 2 for l in range(cfg.text.num_hidden_layers) for k in ("qkv_w", "o_w", "gu_w", "down_w"))
     wbytes += eng.w.t["l.head"].numel() * 2
@@ -435,7 +439,7 @@ def main():
     # extra (not `value`, which stays bf16): the same decode on fp8 (OCP e4m3fn) weight rows with per-row scales -- BASELINE
     # config #5's weight format; half the weight bytes per step
     fp8 = None
-    if not args.no_fp8 and rank == 0:
+    if not args.no_fp8 and rank == 0 and solo:
         del eng
         torch.cuda.empty_cache()
         eng8 = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 1234, dev), dev, batched_decode=True, fp8_decode=True))
@@ -488,7 +492,9 @@ def main():
             "decode_step_hbm": {"algorithmic_bytes": int(wbytes + kv_bytes), "ms": round(dec_ms, 4),
                                 "achieved_GBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
                                 "frac_of_8TBps": round((wbytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None,
-                                "launches_per_layer": 4 if fused_flag else 6},
+                                "launches_per_layer": stages.get("launches_per_layer"),
+                                "fused_attention_layers": stages.get("fused_attention_layers"),
+                                "standalone_attention_layers": stages.get("standalone_attention_layers")},
         }
         if roll:
             rec["rollout"] = roll

@@ -426,6 +426,9 @@ typedef struct {
      * slot `step`, Tmax >= Tnew - 1) instead of a copy of the prompt per row. */
     const void *kprefix, *vprefix;
     int prefix_cap, rows_per_prompt;
+    /* optional HOST array of 4 counters the call adds to: decode forwards, kernel launches inside their layer loops, layers whose
+     * attention half ran as the one-launch block, layers whose attention half ran on the stand-alone kernels */
+    long long* host_stats;
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

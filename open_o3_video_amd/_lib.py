@@ -63,7 +63,7 @@ class DecodeState(C.Structure):
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
                 ("ws_bytes", sz), ("group", i32), ("sync", vp), ("top_k", i32), ("kprefix", vp), ("vprefix", vp),
-                ("prefix_cap", i32), ("rows_per_prompt", i32)]
+                ("prefix_cap", i32), ("rows_per_prompt", i32), ("host_stats", vp)]
 
 
 class PrefillOpts(C.Structure):

@@ -50,6 +50,7 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
+thread_local long long o3v_tl_launches = 0;
 extern "C" int o3v_abi_version(void) { return 6; }
 
 // ------------------------------------------------------------------------------------------------ context handle
@@ -439,6 +440,9 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
     bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
     int step = step0;
+    // host_stats (optional, host memory): [0] += decode forwards, [1] += kernel launches inside their layer loops, [2] += layers whose
+    // attention half ran as the one-launch block, [3] += layers whose attention half ran on the stand-alone kernels
+    long long* hs = (long long*)st->host_stats;
     // attention half of layer l as stand-alone launches: q/k/v (+norm, rope, cache append), attention + merge, o_proj + residual
     auto attention_half = [&](int l) -> int {
         const o3v_llm_layer_w& lw = d->layer[l];
@@ -504,6 +508,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         if (slot0 + step >= st->Tmax) return O3V_ERR_ARG;
         // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
         if (st->do_sample) TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
+        const long long launches0 = o3v_tl_launches;
         for (int l = 0; l < d->layers; ++l) {
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
@@ -528,6 +533,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                     return rc;
             }
             if (!fused) TRY(attention_half(l));
+            if (hs) ++hs[fused ? 2 : 3];
             if (fp8) {
                 TRY(o3v_linear_decode_fp8(st->x, lw.ln2, d->rms_eps, lw.gu_w8, lw.gu_s, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
                                           O3V_EPI_SWIGLU, s));
@@ -552,7 +558,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_linear_decode(w.mlp, nullptr, 0.f, lw.down_w, lw.down_wp, nullptr, st->x, st->x, B, H, I, I, H, H,
                                   O3V_EPI_RESIDUAL, s));
         }
-        TRY(llm_head(d, st->x, H, B, w.normed, st->logits, true, s));
+        if (hs) {
+            ++hs[0];
+            hs[1] += o3v_tl_launches - launches0;
+        }
+        // the head follows the layers: fp8 rows only when the layer stack of this call streams fp8 rows
+        TRY(llm_head(d, st->x, H, B, w.normed, st->logits, fp8 || fp8b, s));
     }
     return O3V_OK;
 }

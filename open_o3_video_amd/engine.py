@@ -481,6 +481,8 @@ class O3VEngine:
                               top_k=max(0, int(top_k or 0)), kprefix=kc0.data_ptr() if shared_prompt else 0,
                               vprefix=vc0.data_ptr() if shared_prompt else 0, prefix_cap=S if shared_prompt else 0,
                               rows_per_prompt=G if shared_prompt else 0)
+        stats = (C.c_longlong * 4)(0, 0, 0, 0)      # decode forwards, launches in their layer loops, fused / stand-alone attention halves
+        st.host_stats = C.cast(stats, C.c_void_p)
         tm["kv_cache_bytes"] = int((kc.numel() + vc.numel() + (kc0.numel() + vc0.numel() if shared_prompt else 0)) * 2)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0
@@ -493,6 +495,10 @@ class O3VEngine:
             if use_eos and done < T and bool(finished.all().item()):
                 break
         mark(3)
+        layers_run = stats[0] * tc.num_hidden_layers
+        tm["decode_forwards"] = int(stats[0])
+        tm["launches_per_layer"] = (stats[1] / layers_run) if layers_run else None
+        tm["fused_attention_layers"], tm["standalone_attention_layers"] = int(stats[2]), int(stats[3])
         if sync is not None:
             code = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
             if code:

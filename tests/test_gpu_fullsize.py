@@ -336,3 +336,51 @@ def test_qwen3vl_8b_dims(need_big_gpu):
         k += 1
     print(f"Qwen3-VL-8B dims: fp8 rows follow the bf16 rows for {k}/24 tokens (margin at the split {m[k] if k < 24 else None})")
     assert k == 24 or m[k] < 16 * floor      # fp8 weights are another model: only a clearly safe margin must survive quantisation
+
+
+def test_qwen3vl_8b_config5_group_on_fp8_rows(need_big_gpu):
+    """BASELINE config #5 at size: Qwen3-VL-8B dimensions, N = 16 self-consistency chains of one question decoded as ONE 16-row group
+    on the fp8 rows (fragment-major fp8 images on the matrix cores, `gemv_mfma_fp8_kernel`).  (1) the prompt's K/V is kept once for
+    the 16 rows; (2) a chain depends on (seed, its index) only -- permuting the rows' indices permutes the chains, bit for bit;
+    (3) the sampled chains differ from each other; (4) under greedy decoding all 16 rows agree with each other, and the fp8 rows
+    follow the bf16 rows wherever the bf16 margin is safe."""
+    from open_o3_video_amd.config import O3VConfig, qwen3vl_8b_dict
+    from open_o3_video_amd.engine import O3VEngine
+    from open_o3_video_amd.weights import DeviceWeights, random_getter
+    cfg = O3VConfig.from_dict(qwen3vl_8b_dict())
+    eng = O3VEngine(cfg, DeviceWeights(cfg, random_getter(cfg, 21, "cuda", std=0.02, head_std=0.08), "cuda", batched_decode=True,
+                                       fp8_decode=True))
+    F, H, W, N, T = 8, 224, 416, 16, 20
+    tpf = (H // 32) * (W // 32)
+    ids = _prompt(cfg, F, tpf, seed=4)
+    S = len(ids)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (F, 3, H, W), generator=gen, dtype=torch.uint8, device="cuda")
+    vis = eng.vit_forward(*eng.pixels_from_frames(frames))
+    grid = np.asarray([[1, H // 16, W // 16]] * F, dtype=np.int64)
+    kw = dict(vis_embeds=vis, image_grid_thw=grid, max_new_tokens=T, num_return_sequences=N)
+    samp = dict(do_sample=True, top_p=0.95, temperature=1.0, top_k=50, seed=3)
+    a = eng.generate([ids], None, row_ids=list(range(N)), **kw, **samp)
+    tc = cfg.text
+    per_tok = 2 * tc.num_hidden_layers * tc.num_key_value_heads * tc.head_dim * 2
+    assert a.timings["kv_cache_bytes"] == per_tok * (S + N * T)              # (1): not N x (S + T)
+    assert a.timings["fused_attention_layers"] == 0 and a.timings["decode_forwards"] == T - 1
+    b = eng.generate([ids], None, row_ids=list(range(N))[::-1], **kw, **samp)
+    assert torch.equal(b.sequences.flip(0), a.sequences)                     # (2)
+    assert len({tuple(r.tolist()) for r in a.sequences[:, S:]}) > N // 2     # (3)
+    g8 = eng.generate([ids], None, **kw)                                     # greedy on the fp8 rows
+    assert all(torch.equal(g8.sequences[i], g8.sequences[0]) for i in range(N))
+    keep = eng.w.llm.layer[0].gu_w8p
+    eng.w.llm.layer[0].gu_w8p = 0                                            # the fp8-rows switch reads layer 0: bf16 rows now
+    try:
+        g16 = eng.generate([ids], None, **kw)
+    finally:
+        eng.w.llm.layer[0].gu_w8p = keep
+    assert all(torch.equal(g16.sequences[i], g16.sequences[0]) for i in range(N))
+    ga, gc, m = g16.sequences[0, S:].tolist(), g8.sequences[0, S:].tolist(), g16.margins[0].tolist()
+    k = 0
+    while k < T and ga[k] == gc[k]:
+        k += 1
+    print(f"Qwen3-VL-8B dims, 16-row group: fp8 rows follow the bf16 rows for {k}/{T} tokens (bf16 margin at the split {m[k] if k < T else None})")
+    floor = 4 * E_MAX_SIGMA * eng.forward_logits(np.asarray([ids]), None, vis_embeds=vis, image_grid_thw=grid)[0, -1].float().std().item()
+    assert k == T or m[k] < 16 * floor   # fp8 weights are another model: only a clearly safe margin must survive quantisation
