@@ -322,14 +322,33 @@ class O3VEngine:
         return logits
 
     # ------------------------------------------------------------------------------------------ generate
+    class _InLaunchWaitGaveUp(_lib.O3VError):
+        pass
+
     @torch.no_grad()
-    def generate(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
+    def generate(self, *args, **kw) -> "GenerateOutput":
+        """`_generate` with one safety net: if an in-launch wait of the one-launch decode block gives up (its waiting workgroups were
+        not all resident -- e.g. another process holds part of the GPU -- and the sticky time-out word is set), the SAME call is
+        run again in this process on the stand-alone kernels (`fused_decode=False` for that call), logged once.  The word is read
+        after the first chunk of steps and at the end, so a starved run is noticed after milliseconds, not after the completion."""
+        try:
+            return self._generate(*args, **kw)
+        except O3VEngine._InLaunchWaitGaveUp as e:
+            if not getattr(self, "_warned_fused_fallback", False):
+                import logging
+                logging.getLogger(__name__).warning("%s; re-running this generate call on the stand-alone decode kernels", e)
+                self._warned_fused_fallback = True
+            self.fused_fallbacks = getattr(self, "fused_fallbacks", 0) + 1
+            return self._generate(*args, **kw, _fused_ok=False)
+
+    @torch.no_grad()
+    def _generate(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None, frames=None,
                  max_new_tokens=16, eos_token_ids: Sequence[int] = (), pad_token_id: Optional[int] = None,
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  top_k: int = 0, num_return_sequences: int = 1, seed: int = 0, row_ids: Optional[Sequence[int]] = None,
                  vis_embeds: Optional[torch.Tensor] = None, steps_per_sync: int = 16, return_margins: bool = True,
                  sync_timings: bool = False, prefix_key=None, pixel_values_videos=None, video_grid_thw=None, video_frames=None,
-                 second_per_grid_ts=None) -> GenerateOutput:
+                 second_per_grid_ts=None, _fused_ok: bool = True) -> GenerateOutput:
         """HF-semantics generate.  `num_return_sequences=G` shares ONE ViT pass and ONE prefill across the G
         completions of a prompt (the reference recomputes both G times, TF:1493-1579) and fans the KV cache out.
 
@@ -466,8 +485,10 @@ class O3VEngine:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         # tickets / mailboxes of the one-launch attention block (batch 1): zeroed once per call, epochs count the launches
         sync = None
-        if self.fused_decode and B == 1:
+        if self.fused_decode and _fused_ok and B == 1:
             sync = torch.zeros(_lib.load().o3v_decode_sync_bytes(), dtype=torch.uint8, device=self.dev)
+            if getattr(self, "_debug_poison_sync", False):     # test hook: tickets that can never reach "last" -> the waits give up
+                sync[:1024].view(torch.int32).fill_(0x40000000)
         st = _lib.DecodeState(B=B, S=S, Tmax=Tmax, Tnew=T, nsplit=nsplit, pad_id=pad_id, n_eos=len(eos_token_ids),
                               do_sample=int(do_sample), rep_penalty=float(repetition_penalty), temperature=float(temperature),
                               top_p=float(top_p), seed=int(seed) & (2 ** 64 - 1), x=xdec.data_ptr(), kcache=kc.data_ptr(),
@@ -488,10 +509,22 @@ class O3VEngine:
         done = 0
         use_eos = len(eos_token_ids) > 0
         chunk = max(1, int(steps_per_sync)) if use_eos else T
+
+        def check_waits():
+            if sync is None:
+                return
+            code = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+            if code:
+                raise O3VEngine._InLaunchWaitGaveUp(f"decode: an in-launch wait gave up (code {code:#x})")
+
         while done < T:
-            n = min(chunk, T - done)
+            # the first chunk is short whenever the one-launch block is in use: its time-out word is read right after it
+            n = min(chunk if (done or sync is None) else min(chunk, 16), T - done)
             _lib.call("o3v_llm_decode", C.byref(self.w.llm), C.byref(st), done, n, int(done + n == T), _stream())
+            first = done == 0
             done += n
+            if first and done < T:
+                check_waits()
             if use_eos and done < T and bool(finished.all().item()):
                 break
         mark(3)
@@ -499,10 +532,7 @@ class O3VEngine:
         tm["decode_forwards"] = int(stats[0])
         tm["launches_per_layer"] = (stats[1] / layers_run) if layers_run else None
         tm["fused_attention_layers"], tm["standalone_attention_layers"] = int(stats[2]), int(stats[3])
-        if sync is not None:
-            code = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
-            if code:
-                raise _lib.O3VError(f"decode: an in-launch wait gave up (code {code:#x}); results are invalid")
+        check_waits()
         gen = out_ids[:, :done].to(torch.int64)
         if use_eos and done > 0:
             # HF stops at the step where every row has finished: trim trailing all-pad columns generated past it

@@ -493,3 +493,28 @@ def test_fp8_rows_batched_decode_engine(need_gpu):
             k += 1
         print(f"fp8 rows, {G} decode rows: follow the bf16 rows for {k}/{n_new} tokens")
         assert k == n_new or m[k] < 2 * LOGIT_ATOL, (G, k, m[k])
+
+
+def test_in_launch_wait_give_up_reruns_on_stand_alone_kernels(need_gpu, golden_dir):
+    """Robustness of the one-launch decode block: when one of its in-launch waits gives up (here forced -- the q/k/v ticket lines of the
+    hand-off buffer are poisoned so that no workgroup ever draws the 'last' ticket and every consumer runs into its bounded spin),
+    generate() notices after the first chunk of steps, re-runs the SAME call in process on the stand-alone kernels and returns the
+    golden ids; the next call uses the one-launch block again.  Nothing hangs: every spin is bounded and the give-up is sticky."""
+    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
+    cfg = fm.medium_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 2))
+    kw = dict(pixel_values=torch.from_numpy(g["pixel_values"]), image_grid_thw=g["grid"], max_new_tokens=16, pad_token_id=cfg["pad_token_id"])
+    ok = eng.generate(g["input_ids"], None, **kw)
+    assert ok.timings["fused_attention_layers"] > 0 and ok.timings["standalone_attention_layers"] == 0
+    assert abs(ok.timings["launches_per_layer"] - 3.0) < 1e-9            # attention block, gate/up, down
+    eng._debug_poison_sync = True
+    try:
+        out = eng.generate(g["input_ids"], None, **kw)
+    finally:
+        eng._debug_poison_sync = False
+    assert eng.fused_fallbacks == 1
+    assert np.array_equal(out.sequences.cpu().numpy(), g["bf16_ids"])
+    assert out.timings["fused_attention_layers"] == 0 and out.timings["standalone_attention_layers"] > 0
+    again = eng.generate(g["input_ids"], None, **kw)
+    assert again.timings["fused_attention_layers"] > 0 and eng.fused_fallbacks == 1
+    assert torch.equal(again.sequences, ok.sequences)
