@@ -213,6 +213,20 @@ int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_
                           int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
                           o3v_stream_t stream);
 
+/* o3v_decode_attn_block with a PREFETCH role: extra workgroups behind the o_proj role (dispatched into the slots the q/k/v role
+ * frees, i.e. when the dependent attention chain starts and HBM goes idle) read pf_bytes of pf_ptr -- the head of the NEXT launch's
+ * weight stream (the layer's gate/up rows, TF:541-554) -- and drop the values, so that those bytes are served from the memory-side
+ * Infinity Cache afterwards.  Results are those of o3v_decode_attn_block (the role writes nothing). */
+int o3v_decode_attn_block_pf(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
+                             const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
+                             float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax,
+                             int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
+                             const void* pf_ptr, size_t pf_bytes, o3v_stream_t stream);
+/* Process-wide knobs of that role as o3v_llm_decode uses it: bytes per layer (0 = role off, the default), load policy (0 default,
+ * 1 non-temporal), workgroups of the role. */
+void o3v_decode_prefetch_config(size_t bytes, int policy, int wgs);
+size_t o3v_decode_prefetch_bytes(void);
+
 /* o3v_decode_attn_block on fp8 (OCP e4m3fn) rows + per-row scales for the q/k/v and o projections (bit-identical to
  * o3v_gemv_norm_qkv_rope_fp8 + o3v_attn_decode + o3v_linear_decode_fp8) */
 int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, const void* qkv_w8, const float* qkv_s, const void* qkv_b,

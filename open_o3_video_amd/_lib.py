@@ -111,6 +111,10 @@ SIGNATURES = {
                                      i32, i32, i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_decode_attn_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                               i32, f32, vp, C.c_uint32, vp],
+    "o3v_decode_attn_block_pf": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                                 i32, f32, vp, C.c_uint32, vp, sz, vp],
+    "o3v_decode_prefetch_config": [sz, i32, i32],
+    "o3v_decode_prefetch_bytes": [],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -138,7 +142,8 @@ SIGNATURES = {
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }
 _RET = {"o3v_ctx_create": vp, "o3v_ctx_destroy": None, "o3v_ctx_llm": C.POINTER(LlmDesc), "o3v_ctx_vit": C.POINTER(VitDesc),
-        "o3v_ctx_vit3": C.POINTER(Vit3Desc), "o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
+        "o3v_ctx_vit3": C.POINTER(Vit3Desc), "o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz,
+        "o3v_decode_prefetch_bytes": sz, "o3v_decode_prefetch_config": None}
 
 SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
 SAMPLE_SCRATCH_FLOATS = 40960   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h

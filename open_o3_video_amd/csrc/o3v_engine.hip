@@ -3,6 +3,7 @@
 // sync -- the whole forward is graph-capturable).  Arithmetic restated from transformers 5.15.0
 // models/qwen2_5_vl/modeling_qwen2_5_vl.py (TF:) -- see include/o3v.h for the per-entry citations.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "../../include/o3v.h"
 
@@ -524,9 +525,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                     : fp8 ? o3v_decode_attn_block_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, lw.o_w8, lw.o_s, st->cosT,
                                                     st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D,
                                                     st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync, epoch, s)
-                        : o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,
-                                                vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step, st->Tmax, st->Tnew,
-                                                step, st->nsplit, scale, st->sync, epoch, s);
+                        : o3v_decode_attn_block_pf(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,
+                                                   vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step, st->Tmax, st->Tnew,
+                                                   step, st->nsplit, scale, st->sync, epoch, lw.gu_w,
+                                                   std::min(o3v_decode_prefetch_bytes(), (size_t)2 * I * H * 2), s);
                 if (rc == O3V_ERR_SHAPE && l == 0)
                     fused = false;  // shapes or residency do not allow the one-launch form: the stand-alone kernels instead
                 else if (rc != O3V_OK)
