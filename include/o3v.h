@@ -213,19 +213,17 @@ int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const void* qkv_
                           int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
                           o3v_stream_t stream);
 
-/* o3v_decode_attn_block with a PREFETCH role: extra workgroups behind the o_proj role (dispatched into the slots the q/k/v role
- * frees, i.e. when the dependent attention chain starts and HBM goes idle) read pf_bytes of pf_ptr -- the head of the NEXT launch's
- * weight stream (the layer's gate/up rows, TF:541-554) -- and drop the values, so that those bytes are served from the memory-side
- * Infinity Cache afterwards.  Results are those of o3v_decode_attn_block (the role writes nothing). */
-int o3v_decode_attn_block_pf(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
-                             const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
-                             float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot, int Tmax,
-                             int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
-                             const void* pf_ptr, size_t pf_bytes, o3v_stream_t stream);
-/* Process-wide knobs of that role as o3v_llm_decode uses it: bytes per layer (0 = role off, the default), load policy (0 default,
- * 1 non-temporal), workgroups of the role. */
-void o3v_decode_prefetch_config(size_t bytes, int policy, int wgs);
-size_t o3v_decode_prefetch_bytes(void);
+/* ---- fp8 x fp8 on the matrix cores (o3v_fp8.hip): the compute-bound linears as W8A8 (vLLM's fp8 linear method for the checkpoints the
+ * reference serves with quantization="fp8"; BASELINE config #5).  OCP e4m3fn; every scale is a power of two. ---- */
+/* q[r, :] = fp8(x[r, :] / scale[r]) with scale[r] = the smallest power of two that brings row r into +-448 (1 for a zero row). */
+int o3v_quantize_rows_fp8(const void* x, void* q, float* scale, int rows, int cols, int ld_in, int ld_q, o3v_stream_t stream);
+/* The same on y = RMSNorm(x) * w with o3v_rmsnorm's arithmetic (TF:65-79): the bf16 values the bf16 path would feed its linears. */
+int o3v_rmsnorm_quantize_fp8(const void* x, const void* w, void* q, float* scale, int rows, int cols, int ld_in, int ld_q, float eps,
+                             o3v_stream_t stream);
+/* out[M, N] = epilogue((A8[M, K] . W8[N, K]^T) * sa[m] * sw[n] + bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), fp32
+ * accumulation; epilogue O3V_EPI_NONE / _RESIDUAL / _SWIGLU as o3v_gemm_bf16.  K % 128 == 0, lda / ldw in bytes (= elements). */
+int o3v_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, const void* bias, const void* res, void* out, int M,
+                 int N, int K, int lda, int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 
 /* o3v_decode_attn_block on fp8 (OCP e4m3fn) rows + per-row scales for the q/k/v and o projections (bit-identical to
  * o3v_gemv_norm_qkv_rope_fp8 + o3v_attn_decode + o3v_linear_decode_fp8) */
@@ -390,7 +388,10 @@ int o3v_llm_prefill(const o3v_llm_desc* d, void* x, const void* cosT, const void
  *  * shared prompt entry: the first prefix_len of the `past` tokens of every row live ONCE per prompt in kprefix / vprefix
  *    ([layers][B / rows_per_prefix][Hkv][prefix_cap][D]); kcache / vcache [layers][B][Hkv][Tmax][D] then hold only the tokens
  *    behind them (this call's S tokens land in slots past - prefix_len ..) -- the G completions of one prompt run behind one
- *    copy of its K/V (R:grpo_trainer.py:601-632).  Tile descriptors keep logical key indexes (k_len = past + S). */
+ *    copy of its K/V (R:grpo_trainer.py:601-632).  Tile descriptors keep logical key indexes (k_len = past + S).
+ *  * w8a8 (BASELINE config #5, "fp8 weights on CDNA4 fp8 MFMA"): 1 = run the four linears of every layer as fp8 x fp8 on the matrix
+ *    cores (o3v_gemm_fp8: per-token activation scales, the per-row weight scales of the fp8 rows) when the descriptor carries fp8
+ *    rows and the widths are whole 128-byte k-tiles, else the bf16 path; 2 = the same but O3V_ERR_SHAPE instead of the bf16 path. */
 typedef struct {
     const int *ds_rows, *ds_src;
     int n_ds;
@@ -399,6 +400,7 @@ typedef struct {
     long ds_stride;
     const void *kprefix, *vprefix;
     int prefix_len, prefix_cap, rows_per_prefix;
+    int w8a8;
 } o3v_prefill_opts;
 int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* cosT, const void* sinT, const int* tiles, int n_tiles,
                        int rows_per_tile, void* kcache, void* vcache, int B, int S, int past, int Tmax,

@@ -68,7 +68,7 @@ class DecodeState(C.Structure):
 
 class PrefillOpts(C.Structure):
     _fields_ = [("ds_rows", vp), ("ds_src", vp), ("n_ds", i32), ("ds_feat", vp), ("n_deep", i32), ("ds_stride", i64),
-                ("kprefix", vp), ("vprefix", vp), ("prefix_len", i32), ("prefix_cap", i32), ("rows_per_prefix", i32)]
+                ("kprefix", vp), ("vprefix", vp), ("prefix_len", i32), ("prefix_cap", i32), ("rows_per_prefix", i32), ("w8a8", i32)]
 
 
 # name -> argtypes (return type int unless listed in _RET)
@@ -111,10 +111,9 @@ SIGNATURES = {
                                      i32, i32, i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_decode_attn_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                               i32, f32, vp, C.c_uint32, vp],
-    "o3v_decode_attn_block_pf": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
-                                 i32, f32, vp, C.c_uint32, vp, sz, vp],
-    "o3v_decode_prefetch_config": [sz, i32, i32],
-    "o3v_decode_prefetch_bytes": [],
+    "o3v_quantize_rows_fp8": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "o3v_rmsnorm_quantize_fp8": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "o3v_gemm_fp8": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -142,8 +141,7 @@ SIGNATURES = {
     "o3v_llm_decode": [C.POINTER(LlmDesc), C.POINTER(DecodeState), i32, i32, i32, vp],
 }
 _RET = {"o3v_ctx_create": vp, "o3v_ctx_destroy": None, "o3v_ctx_llm": C.POINTER(LlmDesc), "o3v_ctx_vit": C.POINTER(VitDesc),
-        "o3v_ctx_vit3": C.POINTER(Vit3Desc), "o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz,
-        "o3v_decode_prefetch_bytes": sz, "o3v_decode_prefetch_config": None}
+        "o3v_ctx_vit3": C.POINTER(Vit3Desc), "o3v_vit_workspace_bytes": sz, "o3v_vit3_workspace_bytes": sz, "o3v_llm_workspace_bytes": sz, "o3v_decode_sync_bytes": sz}
 
 SYNC_TMO_BYTE = 2048            # O3V_SYNC_TMO_BYTE in include/o3v.h
 SAMPLE_SCRATCH_FLOATS = 40960   # O3V_SAMPLE_SCRATCH_FLOATS in include/o3v.h

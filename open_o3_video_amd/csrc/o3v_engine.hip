@@ -274,6 +274,11 @@ extern "C" size_t o3v_llm_workspace_bytes(const o3v_llm_desc* d, int rows) {
     n += align256(R * d->inter * 2);        // mlp
     n += align256(R * H * 2);               // normed (head)
     if (rows > 8 && rows <= SPLITK_MAX_ROWS) n += align256(splitk_bytes(d, rows));  // split-K partials of the few-tile GEMMs
+    if (d->layer && d->layer[0].gu_w8) {    // fp8 rows present: room for the W8A8 prefill (o3v_prefill_opts.w8a8)
+        n += align256(R * (H > QD ? H : QD));   // a8: fp8 activations of the q/k/v, o and gate/up linears
+        n += align256(R * d->inter);            // m8: fp8 SwiGLU output
+        n += align256(R * sizeof(float));       // per-row scales
+    }
     return n;
 }
 
@@ -282,6 +287,8 @@ struct LlmWs {
     char *h, *qkv, *q, *att, *mlp, *normed;
     float* splitk;
     size_t splitk_bytes;
+    char *a8 = nullptr, *m8 = nullptr;  // W8A8 prefill only
+    float* sa = nullptr;
 };
 bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w) {
     const size_t R = rows, H = d->hidden, QD = (size_t)d->heads * d->head_dim, KD = (size_t)d->kv_heads * d->head_dim;
@@ -298,6 +305,12 @@ bool carve_llm(const o3v_llm_desc* d, int rows, void* ws, size_t bytes, LlmWs& w
         w.splitk_bytes = splitk_bytes(d, rows);
         w.splitk = (float*)cv.take(w.splitk_bytes);
         if (!w.splitk) return false;
+    }
+    if (d->layer && d->layer[0].gu_w8) {
+        w.a8 = (char*)cv.take(R * (H > QD ? H : QD));
+        w.m8 = (char*)cv.take(R * d->inter);
+        w.sa = (float*)cv.take(R * sizeof(float));
+        if (!w.sa) return false;
     }
     return w.normed != nullptr;
 }
@@ -336,12 +349,38 @@ extern "C" int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* co
     const size_t layer_stride = (size_t)B * Hkv * Tmax * D * 2;
     const size_t pre_stride = pfx ? (size_t)(B / o.rows_per_prefix) * Hkv * o.prefix_cap * D * 2 : 0;
     const long p_hs = (long)o.prefix_cap * D, p_bs = (long)Hkv * o.prefix_cap * D;
+    // W8A8 (opt-in): the four linears of every layer as fp8 x fp8 on the matrix cores -- activations quantised per token on the fly
+    // (the RMSNorm kernels emit fp8 + a row scale directly), weights = the fp8 rows of the decode; whole 128-byte k-tiles only
+    const bool w8a8 = o.w8a8 && w.sa && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 &&
+                      (H % 128) == 0 && (QD % 128) == 0 && (I % 128) == 0 && rows > 8;
+    if (o.w8a8 && !w8a8 && o.w8a8 > 1) return O3V_ERR_SHAPE;  // w8a8 = 2: required, not merely preferred
     for (int l = 0; l < d->layers; ++l) {
         const o3v_llm_layer_w& lw = d->layer[l];
         char* kc = (char*)kcache + l * layer_stride;
         char* vc = (char*)vcache + l * layer_stride;
         const char* kp = pfx ? (const char*)o.kprefix + l * pre_stride : nullptr;
         const char* vp = pfx ? (const char*)o.vprefix + l * pre_stride : nullptr;
+        if (w8a8) {
+            TRY(o3v_rmsnorm_quantize_fp8(x, lw.ln1, w.a8, w.sa, rows, H, H, H, d->rms_eps, s));
+            TRY(o3v_gemm_fp8(w.a8, w.sa, lw.qkv_w8, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, H, NQKV, 0, O3V_EPI_NONE, s));
+            if (lw.q_norm)
+                TRY(o3v_qkv_norm_rope_cache(w.qkv, lw.q_norm, lw.k_norm, d->rms_eps, cosT, sinT, w.q, kc, vc, own_past, rows, S, Hq, Hkv, D,
+                                            Tmax, S, 0, s));
+            else
+                TRY(o3v_qkv_rope_cache(w.qkv, cosT, sinT, w.q, kc, vc, own_past, rows, S, Hq, Hkv, D, Tmax, S, 0, s));
+            TRY(o3v_attn_tiles_prefix(w.q, kc, vc, kp, vp, p_hs, p_bs, o.prefix_len, pfx ? o.rows_per_prefix : 1, w.att, tiles, n_tiles,
+                                      rows_per_tile, Hq, Hq / Hkv, D, QD, D, (long)Tmax * D, (long)Hkv * Tmax * D, D, (long)Tmax * D,
+                                      (long)Hkv * Tmax * D, QD, scale, s));
+            TRY(o3v_quantize_rows_fp8(w.att, w.a8, w.sa, rows, QD, QD, QD, s));
+            TRY(o3v_gemm_fp8(w.a8, w.sa, lw.o_w8, lw.o_s, nullptr, x, x, rows, H, QD, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+            TRY(o3v_rmsnorm_quantize_fp8(x, lw.ln2, w.a8, w.sa, rows, H, H, H, d->rms_eps, s));
+            TRY(o3v_gemm_fp8(w.a8, w.sa, lw.gu_w8, lw.gu_s, nullptr, nullptr, w.mlp, rows, 2 * I, H, H, H, I, 0, O3V_EPI_SWIGLU, s));
+            TRY(o3v_quantize_rows_fp8(w.mlp, w.m8, w.sa, rows, I, I, I, s));
+            TRY(o3v_gemm_fp8(w.m8, w.sa, lw.down_w8, lw.down_s, nullptr, x, x, rows, H, I, I, I, H, H, O3V_EPI_RESIDUAL, s));
+            if (l < n_deep && n_ds > 0)
+                TRY(o3v_add_rows(x, o.ds_rows, o.ds_src, (const char*)o.ds_feat + (size_t)l * o.ds_stride * 2, n_ds, H, s));
+            continue;
+        }
         TRY(o3v_rmsnorm(x, lw.ln1, w.h, rows, H, H, H, d->rms_eps, s));
         TRY(linear(w.h, lw.qkv_w, lw.qkv_b, nullptr, w.qkv, rows, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s, w.splitk, w.splitk_bytes, d->gemm_tile));
         if (lw.q_norm)
@@ -525,10 +564,9 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                     : fp8 ? o3v_decode_attn_block_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, lw.o_w8, lw.o_s, st->cosT,
                                                     st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D,
                                                     st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync, epoch, s)
-                        : o3v_decode_attn_block_pf(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,
-                                                   vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step, st->Tmax, st->Tnew,
-                                                   step, st->nsplit, scale, st->sync, epoch, lw.gu_w,
-                                                   std::min(o3v_decode_prefetch_bytes(), (size_t)2 * I * H * 2), s);
+                        : o3v_decode_attn_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, st->cosT, st->sinT, w.q, w.att, kc,
+                                                vc, st->part_o, st->part_ml, st->k_lo, H, Hq, Hkv, D, st->S + step, st->Tmax, st->Tnew,
+                                                step, st->nsplit, scale, st->sync, epoch, s);
                 if (rc == O3V_ERR_SHAPE && l == 0)
                     fused = false;  // shapes or residency do not allow the one-launch form: the stand-alone kernels instead
                 else if (rc != O3V_OK)

@@ -50,11 +50,6 @@ struct FusedArgs {
     QkNormRef qk;       // QKN only
     float eps, scale_log2e;
     int H, ctx, nsplit, nb_qkv, nb_attn, nb_o;
-    // prefetch role (workgroups past the o_proj role): touch pf_bytes of the NEXT launch's weight stream (the gate/up rows) so that
-    // they sit in the memory-side Infinity Cache when that launch asks for them; pf_policy 0 default loads, 1 nt, 2 sc1
-    const char* pf_ptr;
-    unsigned long long pf_bytes;
-    int pf_policy;
 #ifdef O3V_STAMPS
     unsigned long long* stamps;  // [grid][8] s_memrealtime ticks (100 MHz)
     int knob;                    // ablations: 1 attention + o_proj roles exit at once, 2 o_proj role exits at once,
@@ -150,33 +145,6 @@ __device__ __forceinline__ void oproj_role(const FusedArgs& a, const int bid) {
     }
 }
 
-// Prefetch role: these workgroups sit behind the o_proj role in the grid, so they are dispatched into the slots the q/k/v
-// workgroups leave -- exactly when the dependent attention chain starts and HBM goes idle (~13 us per layer at 7B).  They read
-// a.pf_bytes of the gate/up weights (the next launch's stream) and throw the values away: the lines stay in the 256 MB
-// memory-side cache.  16 loads of 16 B per lane in flight; nothing waits on this role and it waits on nothing.
-__device__ __forceinline__ void prefetch_role(const FusedArgs& a, const int t, const int n) {
-    const unsigned long long per = ((a.pf_bytes / (unsigned long long)n) + 4095ull) & ~4095ull;   // bytes per workgroup, 4 KiB steps
-    const unsigned long long b0 = per * (unsigned long long)t;
-    unsigned long long b1 = b0 + per;
-    if (b1 > a.pf_bytes) b1 = a.pf_bytes;
-    uint32_t sink = 0;
-    for (unsigned long long off = b0 + (unsigned long long)threadIdx.x * 16ull; off < b1; off += 16ull * 4096ull) {
-        u32x4 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const unsigned long long o = off + (unsigned long long)u * 4096ull;
-            const u32x4* p = reinterpret_cast<const u32x4*>(a.pf_ptr + (o < b1 ? o : b0));
-            if (a.pf_policy == 1)
-                v[u] = __builtin_nontemporal_load(p);
-            else
-                v[u] = *reinterpret_cast<const volatile u32x4*>(p);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) sink ^= v[u][0] ^ v[u][3];
-    }
-    if (sink == 0x9e3779b9u && a.pf_bytes == 1ull) a.sync[SYNC_TMO + 1] = sink;   // never true: keeps the loads alive
-}
-
 // NSTEP: steps of 64 16-byte weight chunks of an o_proj row (K = Hq*D; 512 k per step in bf16, 1024 in fp8); WB: bytes per
 // weight of the two projections.  (Requesting a q/k/v row pair's whole weight stream in one trip was measured and dropped:
 // no faster, and 170+ VGPRs.)
@@ -232,12 +200,8 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
                                     a.nsplit, hk, 0, smem, ho);
         return;
     }
-    if (bid < a.nb_qkv + a.nb_attn + a.nb_o) {
-        oproj_role<NSTEP, WB>(a, bid - a.nb_qkv - a.nb_attn);
-        O3V_STAMP(O3V_STAMP_PTR(a), 3);
-        return;
-    }
-    prefetch_role(a, bid - a.nb_qkv - a.nb_attn - a.nb_o, (int)gridDim.x - a.nb_qkv - a.nb_attn - a.nb_o);
+    oproj_role<NSTEP, WB>(a, bid - a.nb_qkv - a.nb_attn);
+    O3V_STAMP(O3V_STAMP_PTR(a), 3);
 }
 
 // workgroups of this kernel the chip holds at once (0: query failed)
@@ -279,22 +243,13 @@ extern "C" void o3v_fused_set_knob(int k) { g_knob = k; }
 
 extern "C" size_t o3v_decode_sync_bytes(void) { return (size_t)SYNC_WORDS * 4; }
 
-// prefetch role knobs (A/B; o3v_llm_decode reads the byte count): policy 0 default loads / 1 nt, workgroups of the role
-static int g_pf_policy = 0, g_pf_wgs = 160;
-static size_t g_pf_bytes = 0;
-extern "C" void o3v_decode_prefetch_config(size_t bytes, int policy, int wgs) {
-    g_pf_bytes = bytes;
-    g_pf_policy = policy;
-    g_pf_wgs = wgs > 0 ? wgs : 160;
-}
-extern "C" size_t o3v_decode_prefetch_bytes(void) { return g_pf_bytes; }
 
 static int attn_block_launch(void* x, const void* ln_w, float eps, const void* qkv_w, const float* qkv_s, const void* qkv_b,
                              const void* o_w, const float* o_s, const void* q_norm, const void* k_norm, void* kv_raw,
                              const void* cosT, const void* sinT, void* q_buf, void* att_buf,
                              void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv,
                              int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
-                             uint32_t epoch, hipStream_t stream, const void* pf_ptr = nullptr, size_t pf_bytes = 0) {
+                             uint32_t epoch, hipStream_t stream) {
     const int wb = qkv_s ? 1 : 2;
     if ((qkv_s == nullptr) != (o_s == nullptr)) return O3V_ERR_ARG;
     const bool qkn = q_norm != nullptr;
@@ -354,16 +309,7 @@ static int attn_block_launch(void* x, const void* ln_w, float eps, const void* q
     a.stamps = g_stamps;
     a.knob = g_knob;
 #endif
-    // prefetch role: as many workgroups as the q/k/v role frees (they take its slots), 64 KiB per workgroup and trip at least
-    int nb_pf = 0;
-    a.pf_ptr = (const char*)pf_ptr;
-    a.pf_bytes = pf_ptr ? (unsigned long long)pf_bytes : 0ull;
-    a.pf_policy = g_pf_policy;
-    if (a.pf_bytes) {
-        nb_pf = (int)((a.pf_bytes + 65535ull) / 65536ull);
-        if (nb_pf > g_pf_wgs) nb_pf = g_pf_wgs;
-    }
-    const dim3 grid(nb_qkv + nb_attn + nb_o + nb_pf), block(256);
+    const dim3 grid(nb_qkv + nb_attn + nb_o), block(256);
     bool launched = false;
 #define O3V_X(A, B)                                                                                      \
     if (!launched && nstep == A && wb == B) {                                                            \
@@ -400,17 +346,6 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
     return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, nullptr, nullptr, nullptr, cosT, sinT, q_buf, att_buf,
                              kcache, vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync,
                              epoch, stream);
-}
-
-// the same with the prefetch role: pf_bytes of pf_ptr (the weights the NEXT launch streams first) are touched while the chain runs
-extern "C" int o3v_decode_attn_block_pf(void* x, const void* ln_w, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
-                                        const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache, void* vcache,
-                                        float* part_o, float* part_ml, const int* k_lo, int H, int Hq, int Hkv, int D, int slot,
-                                        int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync,
-                                        uint32_t epoch, const void* pf_ptr, size_t pf_bytes, hipStream_t stream) {
-    return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, nullptr, nullptr, nullptr, cosT, sinT, q_buf, att_buf,
-                             kcache, vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync,
-                             epoch, stream, pf_ptr, pf_bytes);
 }
 
 // the same with fp8 (OCP e4m3fn) rows + per-row scales for the two projections (o3v_linear_decode_fp8's weight format)

@@ -73,6 +73,9 @@ class O3VEngine:
         # video rope arithmetic (indexing.rope_index): "tf5" = transformers 5.15 (goldens G5b / G14 / G15), "pinned" = the
         # libraries the reference installs (transformers @336dc69d, vllm 0.7.2).  The facades choose; images do not depend on it.
         self.position_mode = "tf5"
+        # opt-in (BASELINE config #5): the LLM prefill / log-prob linears as fp8 x fp8 on the matrix cores (W8A8: per-token activation
+        # scales, the fp8 rows + per-row scales that fp8_decode builds).  Off by default: the bf16 path and its goldens are untouched.
+        self.fp8_prefill = False
 
     # ------------------------------------------------------------------------------------------ vision
     def _vit_plan(self, grid_thw):
@@ -292,6 +295,10 @@ class O3VEngine:
         nbytes = _lib.load().o3v_llm_workspace_bytes(C.byref(self.w.llm), B * S)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         opts = _lib.PrefillOpts()
+        if self.fp8_prefill:
+            if not getattr(self.w, "fp8_decode", False):
+                raise _lib.O3VError("fp8_prefill needs the fp8 weight rows (DeviceWeights(fp8_decode=True) / quantization='fp8')")
+            opts.w8a8 = 1
         keep = []
         if deepstack is not None and deepstack[1] is not None and deepstack[1].dim() == 3 and deepstack[1].shape[0] > 1:
             ids_all, vis = deepstack

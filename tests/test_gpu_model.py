@@ -500,11 +500,12 @@ def test_in_launch_wait_give_up_reruns_on_stand_alone_kernels(need_gpu, golden_d
     hand-off buffer are poisoned so that no workgroup ever draws the 'last' ticket and every consumer runs into its bounded spin),
     generate() notices after the first chunk of steps, re-runs the SAME call in process on the stand-alone kernels and returns the
     golden ids; the next call uses the one-launch block again.  Nothing hangs: every spin is bounded and the give-up is sticky."""
-    g = np.load(os.path.join(golden_dir, "g7_medium.npz"))
-    cfg = fm.medium_config()
-    eng = build_engine(cfg, fm.make_weights(cfg, 2))
-    kw = dict(pixel_values=torch.from_numpy(g["pixel_values"]), image_grid_thw=g["grid"], max_new_tokens=16, pad_token_id=cfg["pad_token_id"])
+    g = np.load(os.path.join(golden_dir, "g11_tied3b.npz"))       # 16 query heads of 128: a shape the one-launch block is built for
+    cfg = fm.tied3b_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 4))
+    kw = dict(pixel_values=torch.from_numpy(g["pixel_values"]), image_grid_thw=g["grid"], max_new_tokens=12, pad_token_id=cfg["pad_token_id"])
     ok = eng.generate(g["input_ids"], None, **kw)
+    assert np.array_equal(ok.sequences.cpu().numpy(), g["bf16_ids"])
     assert ok.timings["fused_attention_layers"] > 0 and ok.timings["standalone_attention_layers"] == 0
     assert abs(ok.timings["launches_per_layer"] - 3.0) < 1e-9            # attention block, gate/up, down
     eng._debug_poison_sync = True
