@@ -352,7 +352,7 @@ extern "C" int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* co
     // W8A8 (opt-in): the four linears of every layer as fp8 x fp8 on the matrix cores -- activations quantised per token on the fly
     // (the RMSNorm kernels emit fp8 + a row scale directly), weights = the fp8 rows of the decode; whole 128-byte k-tiles only
     const bool w8a8 = o.w8a8 && w.sa && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 &&
-                      (H % 128) == 0 && (QD % 128) == 0 && (I % 128) == 0 && rows > 8;
+                      (H % 128) == 0 && (QD % 128) == 0 && (I % 128) == 0;  // any row count: a log-prob must not depend on its chunk's size
     if (o.w8a8 && !w8a8 && o.w8a8 > 1) return O3V_ERR_SHAPE;  // w8a8 = 2: required, not merely preferred
     for (int l = 0; l < d->layers; ++l) {
         const o3v_llm_layer_w& lw = d->layer[l];

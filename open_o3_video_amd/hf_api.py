@@ -103,7 +103,8 @@ class Qwen2_5_VLForConditionalGeneration:
 
     # ---- construction
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=None, attn_implementation=None, use_cache=True, device="cuda", fp8_decode=False, **_):
+    def from_pretrained(cls, path, torch_dtype=None, attn_implementation=None, use_cache=True, device="cuda", fp8_decode=False,
+                        fp8_prefill=False, **_):
         """Local checkpoint directory only (config.json + *.safetensors).  `attn_implementation` is accepted and
         ignored: attention always runs in the hand-written HIP kernels."""
         if not os.path.isdir(path):
@@ -111,8 +112,10 @@ class Qwen2_5_VLForConditionalGeneration:
         if torch_dtype not in (None, torch.bfloat16, "bfloat16", "auto"):
             raise ValueError("the MI355X path computes in bf16 (torch_dtype=torch.bfloat16)")
         cfg = O3VConfig.from_pretrained(path)
-        w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device, fp8_decode=bool(fp8_decode))
+        w = DeviceWeights(cfg, getter_from_safetensors_dir(path), device, fp8_decode=bool(fp8_decode or fp8_prefill))
         model = cls(cfg, O3VEngine(cfg, w))
+        # opt-in W8A8 prefill / log-prob pass on the fp8 matrix cores (BASELINE config #5); the bf16 path is the default
+        model.engine.fp8_prefill = bool(fp8_prefill)
         gc = load_generation_config(path)
         if gc:
             model.generation_config = GenerationConfigLike(**gc)

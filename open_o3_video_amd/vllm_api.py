@@ -71,7 +71,7 @@ class LLM:
                  max_num_seqs: int = 8, engine: Optional[O3VEngine] = None, tokenizer: Any = None,
                  min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280, device="cuda",
                  enable_prefix_caching: bool = True, quantization: Optional[str] = None, mm_processor_kwargs: Optional[dict] = None,
-                 position_mode: str = "pinned", **_):
+                 position_mode: str = "pinned", fp8_prefill: bool = False, **_):
         if tensor_parallel_size != 1:
             raise ValueError("the reference runs tensor_parallel_size=1 (R:eval/models/model_vllm.py:21); data parallelism "
                              "is one engine per GPU (open_o3_video_amd.dist)")
@@ -86,6 +86,11 @@ class LLM:
             if quantization not in (None, "fp8"):
                 raise ValueError(f"quantization={quantization!r}: only None or 'fp8' (decode rows) is built")
             engine = O3VEngine(cfg, DeviceWeights(cfg, getter_from_safetensors_dir(model), device, fp8_decode=quantization == "fp8"))
+            # vLLM's fp8 linears quantise the activations per token as well (W8A8); here that is opt-in for the compute-bound
+            # prefill (fp8 x fp8 on the matrix cores), while the decode keeps bf16 activations on the exactly widened fp8 rows
+            if fp8_prefill and quantization != "fp8":
+                raise ValueError("fp8_prefill=True needs quantization='fp8'")
+            engine.fp8_prefill = bool(fp8_prefill)
             tokenizer = tokenizer or _load_tokenizer(model)
             pp = os.path.join(model, "preprocessor_config.json")
             if os.path.exists(pp):

@@ -153,9 +153,18 @@ class KVCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def text_forward(W, cfg, inputs_embeds, position_ids, attention_mask_2d, cache, dtype, taps=None):
+def text_forward(W, cfg, inputs_embeds, position_ids, attention_mask_2d, cache, dtype, taps=None, quant=None):
     """TF:790-872 language model + TF:602-757 layers.  inputs_embeds [B,L,H];
-    position_ids [3,B,L]; attention_mask_2d [B, past+L] (1 = real token)."""
+    position_ids [3,B,L]; attention_mask_2d [B, past+L] (1 = real token).
+    quant="w8a8": the four linears of every layer through oracle/quant_ref.linear_w8a8 (the opt-in fp8 prefill)."""
+    if quant == "w8a8":
+        from . import quant_ref
+
+        def lin(x, w, b=None):
+            return quant_ref.linear_w8a8(x, w, b)
+    else:
+        def lin(x, w, b=None):
+            return F.linear(x, w, b)
     tc = cfg["text_config"]
     H, nh, nkv = tc["hidden_size"], tc["num_attention_heads"], tc["num_key_value_heads"]
     hd = H // nh
@@ -180,9 +189,9 @@ def text_forward(W, cfg, inputs_embeds, position_ids, attention_mask_2d, cache, 
         b = f"{p}layers.{li}."
         res = x
         h = rmsnorm(x, W[b + "input_layernorm.weight"].to(dtype), eps)
-        q = F.linear(h, W[b + "self_attn.q_proj.weight"].to(dtype), W[b + "self_attn.q_proj.bias"].to(dtype))
-        k = F.linear(h, W[b + "self_attn.k_proj.weight"].to(dtype), W[b + "self_attn.k_proj.bias"].to(dtype))
-        v = F.linear(h, W[b + "self_attn.v_proj.weight"].to(dtype), W[b + "self_attn.v_proj.bias"].to(dtype))
+        q = lin(h, W[b + "self_attn.q_proj.weight"].to(dtype), W[b + "self_attn.q_proj.bias"].to(dtype))
+        k = lin(h, W[b + "self_attn.k_proj.weight"].to(dtype), W[b + "self_attn.k_proj.bias"].to(dtype))
+        v = lin(h, W[b + "self_attn.v_proj.weight"].to(dtype), W[b + "self_attn.v_proj.bias"].to(dtype))
         q = q.view(B, L, nh, hd).transpose(1, 2)
         k = k.view(B, L, nkv, hd).transpose(1, 2)
         v = v.view(B, L, nkv, hd).transpose(1, 2)
@@ -193,13 +202,13 @@ def text_forward(W, cfg, inputs_embeds, position_ids, attention_mask_2d, cache, 
         vr = v[:, :, None].expand(B, nkv, rep, T, hd).reshape(B, nh, T, hd)
         a = _sdpa_eager(q, kr, vr, hd ** -0.5, mask)
         a = a.transpose(1, 2).reshape(B, L, -1)
-        a = F.linear(a, W[b + "self_attn.o_proj.weight"].to(dtype))
+        a = lin(a, W[b + "self_attn.o_proj.weight"].to(dtype))
         x = res + a
         res = x
         h = rmsnorm(x, W[b + "post_attention_layernorm.weight"].to(dtype), eps)
-        g = F.linear(h, W[b + "mlp.gate_proj.weight"].to(dtype))
-        u = F.linear(h, W[b + "mlp.up_proj.weight"].to(dtype))
-        m = F.linear(F.silu(g) * u, W[b + "mlp.down_proj.weight"].to(dtype))
+        g = lin(h, W[b + "mlp.gate_proj.weight"].to(dtype))
+        u = lin(h, W[b + "mlp.up_proj.weight"].to(dtype))
+        m = lin(F.silu(g) * u, W[b + "mlp.down_proj.weight"].to(dtype))
         x = res + m
         if taps is not None:
             taps[f"llm_layer_{li}_p{past}"] = x.clone()
@@ -344,7 +353,7 @@ def generate(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, ma
 
 
 def full_logits(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw, dtype=torch.float32, pixel_values_videos=None,
-                video_grid_thw=None, second_per_grid_ts=None):
+                video_grid_thw=None, second_per_grid_ts=None, quant=None):
     """model(input_ids, ...).logits [B,L,V] as R:grpo_trainer.py:375 calls it."""
     input_ids = torch.as_tensor(input_ids, dtype=torch.long)
     B, S = input_ids.shape
@@ -355,7 +364,7 @@ def full_logits(W, cfg, input_ids, attention_mask, pixel_values, image_grid_thw,
                         None if pixel_values_videos is None else video_grid_thw, second_per_grid_ts)
     cache = KVCache(cfg["text_config"]["num_hidden_layers"])
     x = embed_with_vision(W, cfg, input_ids, pixel_values, image_grid_thw, dtype, None, pixel_values_videos, video_grid_thw)
-    h = text_forward(W, cfg, x, pos, attention_mask, cache, dtype)
+    h = text_forward(W, cfg, x, pos, attention_mask, cache, dtype, quant=quant)
     return F.linear(h, lm_head_weight(W, cfg).to(dtype))
 
 

@@ -204,6 +204,74 @@ if "q3" in which:
         del eng
         torch.cuda.empty_cache()
 
+if "fp8prefill" in which:
+    # VERDICT r2 item 6 / BASELINE config #5 ("fp8 weights on CDNA4 fp8 MFMA"): the LLM prefill with its linears as fp8 x fp8 on the
+    # matrix cores (engine.fp8_prefill, W8A8) against the bf16 prefill, at 7B and at Qwen3-VL-8B dims; then the GEMM rates of
+    # the four linear shapes of a layer (TFLOP/s; roofline: dense fp8 peak 5 PFLOP/s, bf16 2.5, MI355X_MICROARCH.md Matrix cores).
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.config import qwen3vl_8b_dict
+    del eng
+    torch.cuda.empty_cache()
+    for name, cd, H, W, fac in (("7B", qwen25vl_7b_dict(), 224, 420, 28), ("Qwen3-VL-8B", qwen3vl_8b_dict(), 224, 416, 32)):
+        c = O3VConfig.from_dict(cd)
+        e = O3VEngine(c, DeviceWeights(c, random_getter(c, 1234, dev), dev, batched_decode=False, fp8_decode=True))
+        tpf = (H // fac) * (W // fac)
+        ids = build_prompt(c, 32, tpf, 32 * (tpf + 15) + 170)
+        g = torch.Generator(device=dev).manual_seed(1)
+        frames = torch.randint(0, 256, (32, 3, H, W), generator=g, dtype=torch.uint8, device=dev)
+        res = {}
+        for flag in (False, True):
+            e.fp8_prefill = flag
+            best = None
+            for _ in range(3):
+                out = e.generate([ids], None, frames=frames, max_new_tokens=2, return_margins=False, sync_timings=True)
+                best = out.timings["prefill_ms"] if best is None else min(best, out.timings["prefill_ms"])
+            res["w8a8" if flag else "bf16"] = round(best, 2)
+        tc = c.text
+        S = len(ids)
+        lin_flop = 2.0 * S * tc.num_hidden_layers * (tc.hidden_size * (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim +
+                                                      tc.num_attention_heads * tc.head_dim * tc.hidden_size + 3 * tc.hidden_size * tc.intermediate_size)
+        print(json.dumps({"config": f"prefill {name} dims, S={S}", "prefill_ms": res, "speedup": round(res["bf16"] / res["w8a8"], 3),
+                          "linear_TFLOP": round(lin_flop / 1e12, 2)}), flush=True)
+        # per-shape GEMM rates on this model's widths
+        lib = _lib.load()
+        M = S
+        Hd, QD, I = tc.hidden_size, tc.num_attention_heads * tc.head_dim, tc.intermediate_size
+        NQ = (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        for tag, N, K in (("qkv", NQ, Hd), ("o_proj", Hd, QD), ("gate/up", 2 * I, Hd), ("down", Hd, I)):
+            a16 = torch.randn((M, K), device=dev).to(torch.bfloat16)
+            w16 = (torch.randn((N, K), device=dev) / K ** 0.5).to(torch.bfloat16)
+            a8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev)
+            w8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev)
+            sa, sw = torch.ones(M, device=dev), torch.ones(N, device=dev)
+            n_out = N // 2 if tag == "gate/up" else N
+            epi = 3 if tag == "gate/up" else 0
+            o = torch.empty((M, n_out), dtype=torch.bfloat16, device=dev)
+            rates = {}
+            for kind in ("bf16", "fp8"):
+                def call():
+                    if kind == "bf16":
+                        return lib.o3v_gemm_bf16(P(a16), P(w16), None, None, P(o), M, N, K, K, K, n_out, 0, epi, st)
+                    return lib.o3v_gemm_fp8(P(a8), P(sa), P(w8), P(sw), None, None, P(o), M, N, K, K, K, n_out, 0, epi, st)
+                assert call() == 0
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(10):
+                    call()
+                ev1.record()
+                torch.cuda.synchronize()
+                ms = ev0.elapsed_time(ev1) / 10
+                rates[kind] = round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1)
+            print(json.dumps({"gemm": f"{name} {tag} M={M} N={N} K={K}", "TFLOP_per_s": rates,
+                              "frac_of_peak": {"bf16": round(rates["bf16"] / 2500, 3), "fp8": round(rates["fp8"] / 5000, 3)}}), flush=True)
+        del e
+        torch.cuda.empty_cache()
+    sys.exit(0)
+
 if "rollout_long" in which:
     # G = 16 completions behind a 20k-token prompt (256 frames 224x224) -- the prompt's K/V is kept once
     # (kv_cache_GB counts the shared entry + the 16 rows' own tokens; one prompt's K/V at S = 20394 is 1.17 GB)
