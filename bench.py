@@ -168,6 +168,34 @@ def kernel_roofline(eng, reps=3):
             "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
 
 
+def fp8_gemm_roofline(tc, S, dev):
+    """o3v_gemm_fp8 on the gate/up shape of a layer (M = S prompt tokens): 10 launches between HIP events on the launch stream."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    lib = _lib.load()
+    M, N, K = int(S), 2 * tc.intermediate_size, tc.hidden_size
+    a8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev)
+    w8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev)
+    sa, sw = torch.ones(M, device=dev), torch.ones(N, device=dev)
+    o = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    call = lambda: lib.o3v_gemm_fp8(P(a8), P(sa), P(w8), P(sw), None, None, P(o), M, N, K, K, K, N // 2, 0, 3, st)
+    assert call() == 0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(10):
+        call()
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) / 10 * 1e3
+    tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "gemm256_fp8_kernel<SWIGLU> (v_mfma_scale_f32_16x16x128_f8f6f4; LLM gate/up projection of the W8A8 prefill)",
+            "achieved": round(tf, 1), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(tf / 5000.0, 4), "flop_per_launch": 2.0 * M * N * K,
+            "avg_launch_us": round(us, 1), "traffic": None}
+
+
 def cpu_baseline_config1(new_tokens=32):
     """BASELINE config #1 timed IN FULL on the host cores: Qwen2.5-VL-3B dims (32 ViT blocks, 36 LLM layers, tied
     embeddings), 4 frames 364x644 (4784 patches -> 1196 visual tokens), the whole prompt, `new_tokens` greedy decode steps,
@@ -466,6 +494,20 @@ def main():
         tg = time.perf_counter() - tg
         fp8["group_g8"] = {"new_tokens": 256, "tokens_per_s": round(8 * 256 / tg, 1),
                            "decode_ms_per_step": round(og.timings["decode_ms"] / 256, 3)}
+        # opt-in W8A8 prefill (fp8 x fp8 on the matrix cores, per-token activation scales): prefill time against the bf16 prefill of
+        # the same engine, and the roofline of its GEMM on the layer's gate/up shape against the dense fp8 peak
+        pre = {}
+        for flag in (False, True):
+            eng8.fp8_prefill = flag
+            best = None
+            for _ in range(2):
+                tt = eng8.generate([ids], None, frames=videos[0], max_new_tokens=2, return_margins=False, sync_timings=True).timings
+                best = tt["prefill_ms"] if best is None else min(best, tt["prefill_ms"])
+            pre["w8a8" if flag else "bf16"] = round(best, 2)
+        eng8.fp8_prefill = False
+        fp8["prefill_ms"] = pre
+        fp8["prefill_speedup"] = round(pre["bf16"] / pre["w8a8"], 3)
+        fp8["roofline_fp8_gemm"] = fp8_gemm_roofline(tc8, S, dev)
         del eng8
 
     if rank == 0:
