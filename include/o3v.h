@@ -225,6 +225,19 @@ int o3v_rmsnorm_quantize_fp8(const void* x, const void* w, void* q, float* scale
 int o3v_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, const void* bias, const void* res, void* out, int M,
                  int N, int K, int lda, int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 
+/* The PERSISTENT layer block: RMSNorm + q/k/v (+bias, M-RoPE, cache append) -> attention -> merge -> o_proj + residual -> RMSNorm +
+ * gate/up + SwiGLU of one decode layer at batch 1 as ONE launch (TF:692-757 up to the SwiGLU; down_proj + residual is the next
+ * launch).  The grid is what the chip holds (three 256-thread workgroups per CU); every wave owns a static list of weight rows over
+ * the three projections and keeps its next three rows in flight in registers -- also across the in-launch hand-offs, so ~60 MB of
+ * o_proj / gate/up rows stream while the dependent attention chain runs.  act: bf16 [I] (input of down_proj).  Same arithmetic as
+ * o3v_decode_attn_block + o3v_linear_decode(gate/up): bit-identical.  O3V_ERR_SHAPE unless head_dim 128, hidden == Hq*D a multiple of
+ * 512 (2048, 3584) and the grid is resident: call the other entries instead.  sync: as o3v_decode_attn_block (its own ticket lines). */
+int o3v_decode_layer_block(void* x, const void* ln1, float eps, const void* qkv_w, const void* qkv_b, const void* o_w, const void* ln2,
+                           const void* gu_w, void* act, const void* cosT, const void* sinT, void* q_buf, void* att_buf, void* kcache,
+                           void* vcache, float* part_o, float* part_ml, const int* k_lo, int H, int I, int Hq, int Hkv, int D, int slot,
+                           int Tmax, int cs_stride_row, int cs_off, int nsplit, float scale, uint32_t* sync, uint32_t epoch,
+                           o3v_stream_t stream);
+
 /* o3v_decode_attn_block on fp8 (OCP e4m3fn) rows + per-row scales for the q/k/v and o projections (bit-identical to
  * o3v_gemv_norm_qkv_rope_fp8 + o3v_attn_decode + o3v_linear_decode_fp8) */
 int o3v_decode_attn_block_fp8(void* x, const void* ln_w, float eps, const void* qkv_w8, const float* qkv_s, const void* qkv_b,
@@ -445,6 +458,9 @@ typedef struct {
     /* optional HOST array of 4 counters the call adds to: decode forwards, kernel launches inside their layer loops, layers whose
      * attention half ran as the one-launch block, layers whose attention half ran on the stand-alone kernels */
     long long* host_stats;
+    /* bit 0: batch-1 bf16 decode may use the persistent layer block (o3v_decode_layer_block) where its shapes allow, then one
+     * launch for the attention half + gate/up and one for down_proj per layer; otherwise o3v_decode_attn_block + two launches */
+    int flags;
 } o3v_decode_state;
 
 /* GenerationMixin._sample loop, TF:generation/utils.py:2783-2942, steps [step0, step0+n_steps): sample from

@@ -63,7 +63,7 @@ class DecodeState(C.Structure):
                 ("cur_tok", vp), ("finished", vp), ("out_ids", vp), ("margins", vp), ("eos_ids", vp), ("k_lo", vp),
                 ("row_id", vp), ("part_o", vp), ("part_ml", vp), ("sample_scratch", vp), ("workspace", vp),
                 ("ws_bytes", sz), ("group", i32), ("sync", vp), ("top_k", i32), ("kprefix", vp), ("vprefix", vp),
-                ("prefix_cap", i32), ("rows_per_prompt", i32), ("host_stats", vp)]
+                ("prefix_cap", i32), ("rows_per_prompt", i32), ("host_stats", vp), ("flags", i32)]
 
 
 class PrefillOpts(C.Structure):
@@ -114,6 +114,8 @@ SIGNATURES = {
     "o3v_quantize_rows_fp8": [vp, vp, vp, i32, i32, i32, i32, vp],
     "o3v_rmsnorm_quantize_fp8": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "o3v_gemm_fp8": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_decode_layer_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                               i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "o3v_sample_greedy_embed": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp],
     "o3v_gemv_norm_qkv_rope": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -479,6 +479,8 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     const bool fp8b = B >= 4 && d->layer[0].gu_w8p && d->layer[0].down_w8p && d->layer[0].o_w8p;
     const bool qk_norm = d->layer[0].q_norm != nullptr;  // Qwen3-VL: per-head RMSNorm between the q/k/v linear and the rotation
     bool fused = st->sync && B == 1 && st->group <= 1 && st->nsplit > 0;
+    // the persistent layer block (attention half + gate/up in one launch): bf16 rows, no q/k norm
+    bool layer_block = fused && (st->flags & 1) && !fp8 && !qk_norm;
     int step = step0;
     // host_stats (optional, host memory): [0] += decode forwards, [1] += kernel launches inside their layer loops, [2] += layers whose
     // attention half ran as the one-launch block, [3] += layers whose attention half ran on the stand-alone kernels
@@ -553,6 +555,22 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             const o3v_llm_layer_w& lw = d->layer[l];
             char* kc = (char*)st->kcache + l * layer_stride;
             char* vc = (char*)st->vcache + l * layer_stride;
+            if (layer_block) {
+                const uint32_t epoch = (uint32_t)(step * d->layers + l + 1);
+                const int rc = o3v_decode_layer_block(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_b, lw.o_w, lw.ln2, lw.gu_w, w.mlp, st->cosT,
+                                                      st->sinT, w.q, w.att, kc, vc, st->part_o, st->part_ml, st->k_lo, H, I, Hq, Hkv, D,
+                                                      st->S + step, st->Tmax, st->Tnew, step, st->nsplit, scale, st->sync, epoch, s);
+                if (rc == O3V_ERR_SHAPE && l == 0 && step == step0) {
+                    layer_block = false;  // shapes or residency: the role-per-workgroup block (or the stand-alone kernels) instead
+                } else if (rc != O3V_OK) {
+                    return rc;
+                } else {
+                    if (hs) ++hs[2];
+                    TRY(o3v_linear_decode(w.mlp, nullptr, 0.f, lw.down_w, lw.down_wp, nullptr, st->x, st->x, B, H, I, I, H, H,
+                                          O3V_EPI_RESIDUAL, s));
+                    continue;
+                }
+            }
             if (fused) {
                 const uint32_t epoch = (uint32_t)(step * d->layers + l + 1);
                 const int rc =

@@ -32,8 +32,8 @@ constexpr int SYNC_ATT = 8 * O3V_SYNC_STRIDE;          // [8] ticket lines: kv h
 constexpr int SYNC_TMO = 16 * O3V_SYNC_STRIDE;         // sticky time-out word (byte 2048 = O3V_SYNC_TMO_BYTE)
 constexpr int SYNC_ATT2 = 24 * O3V_SYNC_STRIDE;        // [8] ticket lines: kv head g <- its merged slices
 constexpr int SYNC_BOX_ATT = 32 * O3V_SYNC_STRIDE;     // [512] mailbox lines of the attention workgroups (kv head, split)
-constexpr int SYNC_BOX_O = (32 + 512) * O3V_SYNC_STRIDE;  // [512] mailbox lines of the o_proj workgroups, word hk per kv head
-constexpr int SYNC_WORDS = (32 + 512 + 512) * O3V_SYNC_STRIDE;
+constexpr int SYNC_BOX_O = (32 + 512) * O3V_SYNC_STRIDE;  // [1024] mailbox lines of the o_proj workgroups, word hk per kv head
+constexpr int SYNC_WORDS = (32 + 512 + 1024) * O3V_SYNC_STRIDE;
 constexpr int ATTN_LDS = 4 * 32 * 288;                 // attn_decode_mfma_body: 4 V slices (merge + combine scratch inside)
 
 struct FusedArgs {
@@ -218,6 +218,389 @@ int fused_capacity(size_t shmem) {
 
 }  // namespace
 
+// ================================================================================================
+// Layer block: q/k/v -> attention -> merge -> o_proj -> RMSNorm -> gate/up (SwiGLU) of ONE decode layer as ONE launch whose
+// workgroups are PERSISTENT and IDENTICAL: the grid is exactly what the chip holds (3 workgroups of 256 threads per CU), every
+// wave owns a static list of weight rows across the three projections and keeps its next three rows (3 x 7 KiB at K = 3584) in
+// flight in registers at all times -- also while the workgroup waits at a hand-off.  That is what the role-per-workgroup block
+// above cannot do: there the HBM idles for the ~13 us of the dependent attention chain (only o_proj's 26 MB are preloaded) and
+// the gate/up launch pays a boundary and a ramp; here ~64 MB of o_proj / gate/up rows stream under the chain and the gate/up
+// rows simply continue.  Rows and arithmetic are those of gemv_body (chunk lane + 64 i, i ascending, wave sum; the epilogues and
+// the RMSNorm prologues copied term by term), the attention is attn_decode_mfma_body<true> itself: results are bit-identical to
+// o3v_decode_attn_block + o3v_linear_decode(gate/up).
+//
+// Workgroups [0, nb_attn) also run one (kv head, context split) attention item between their q/k/v rows and their gate/up rows
+// (they own no o_proj row and start streaming again after the chain); the others own the o_proj rows.  Hand-offs (protocol of
+// o3v_handoff.h): E1 all workgroups -> attention items (q, new K/V row), E2 / E3 inside the attention body, E4 o_proj owners ->
+// everybody (the residual stream x').  A workgroup takes its ticket only when its waves have no young loads in flight (the rows
+// requested before are long there), so the store drain (vmcnt(0)) costs no memory latency.
+// ================================================================================================
+constexpr int SYNC_O_DONE = 17 * O3V_SYNC_STRIDE;   // ticket line: workgroups that own o_proj rows
+constexpr int SYNC_QKV_ALL = 18 * O3V_SYNC_STRIDE;  // ticket line: every workgroup's q/k/v rows
+constexpr int BOX_XREADY = 12;                      // mailbox word: the residual stream after o_proj is in memory
+constexpr int LB_RED = 8192;                        // LDS: [0, 8192) the operand vector (K <= 4096), then the norm's scratch
+
+struct LayerArgs {
+    FusedArgs f;  // q/k/v, attention and o_proj operands as in the block above (nb_qkv / nb_o unused)
+    const bf16_t *ln2, *gu_w;
+    bf16_t* act;  // [I] SwiGLU output (input of down_proj, the next launch)
+    int I, n_wg;
+};
+
+// rows a wave consumes after its q/k/v pair, in order: its o_proj rows (at most two), then its (gate, up) pairs
+enum { SU_NONE = 0, SU_O = 1, SU_G = 2, SU_U = 3 };
+struct SubUnit {
+    int kind, row;
+};
+struct RowEnum {
+    int G, NW, Go, NWo, No, Pg, k, cur, phase;  // phase 0: o_proj rows, 1: gate row next, 2: up row next, 3: done
+    __device__ __forceinline__ int gu_pair(int kk) const {
+        const int full = Pg / NW, rem = Pg - full * NW;
+        if (kk < full) return kk * NW + G;
+        if (kk == full && rem > 0) {  // the last, partial round goes to every stride-th wave: no workgroup gets a whole extra round
+            const int stride = NW / rem;
+            if (G % stride == 0 && G / stride < rem) return full * NW + G / stride;
+        }
+        return -1;
+    }
+    __device__ __forceinline__ SubUnit next() {
+        if (phase == 0) {
+            const int r = Go >= 0 ? Go + k * NWo : No;
+            if (r < No) {
+                ++k;
+                return SubUnit{SU_O, r};
+            }
+            phase = 1;
+            k = 0;
+        }
+        if (phase == 1) {
+            const int p = gu_pair(k);
+            if (p < 0) {
+                phase = 3;
+                return SubUnit{SU_NONE, 0};
+            }
+            cur = (p >> 4) * 32 + (p & 15);  // gate row of output column p in the 16-row interleaved weight; its up row is + 16
+            phase = 2;
+            return SubUnit{SU_G, cur};
+        }
+        if (phase == 2) {
+            phase = 1;
+            ++k;
+            return SubUnit{SU_U, cur + 16};
+        }
+        return SubUnit{SU_NONE, 0};
+    }
+};
+
+// RMSNorm of a K-vector into LDS exactly as gemv_body's NORM prologue does it for M = 1 with NT threads (NT / 64 waves): the
+// per-thread fmaf chains, the wave sums and the order in which the wave sums are added.  SC1: x was produced in this launch.
+template <int NT, bool SC1>
+__device__ __forceinline__ void rmsnorm_to_lds(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, float eps, int K, char* smem) {
+    constexpr int XC = (512 + NT - 1) / NT, NWN = NT / 64;
+    const int nxc = K >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* red = reinterpret_cast<float*>(smem + LB_RED);
+    u32x4 xr[XC];  // (the norm weights are fetched at store time: this code runs with a wave's weight rows live in registers)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, K * 2, 0x00020000);
+    if (tid < NT) {
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            const int c = tid + i * NT;
+            if (SC1)
+                xr[i] = load16_sc1(xrs, c < nxc ? (uint32_t)c * 16 : O3V_OOB);
+            else
+                xr[i] = c < nxc ? *reinterpret_cast<const u32x4*>(x + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XC; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ss = fmaf(bf_lo(xr[i][j]), bf_lo(xr[i][j]), ss);
+                ss = fmaf(bf_hi(xr[i][j]), bf_hi(xr[i][j]), ss);
+            }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+    }
+    __syncthreads();
+    if (tid < NT) {
+        float t = red[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NWN; ++w2) t += red[w2];
+        const float rstd = 1.0f / sqrtf(t / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+            const int c = tid + i * NT;
+            if (c < nxc) {
+                const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = pack_bf2(bf_lo(wn[j]) * rbf(bf_lo(xr[i][j]) * rstd), bf_hi(wn[j]) * rbf(bf_hi(xr[i][j]) * rstd));
+                *reinterpret_cast<u32x4*>(smem + (size_t)c * 16) = o;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// one weight row of NS whole steps (K = 512 NS) in registers: requested with non-temporal loads, multiplied with the operand
+// vector in LDS in gemv_body's order (chunk lane + 64 i, i ascending), then the wave sum
+template <int NS>
+__device__ __forceinline__ void lb_load(u32x4 (&b)[NS], const bf16_t* __restrict__ W, int row) {
+    const u32x4* wp = reinterpret_cast<const u32x4*>(W + (size_t)row * (NS * 512)) + (threadIdx.x & 63);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) b[s2] = __builtin_nontemporal_load(wp + s2 * 64);
+}
+template <int NS>
+__device__ __forceinline__ float lb_dot(const u32x4 (&b)[NS], const char* vec) {
+    const char* vp = vec + (size_t)(threadIdx.x & 63) * 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(vp + s2 * 1024);
+        fma8(b[s2], xv, acc);
+        if (s2 & 1) asm volatile("" ::: "memory");  // two operand chunks in flight, not all of them: the registers hold weight rows
+    }
+    return wave_sum(acc);
+}
+
+// the residual stream after o_proj is complete -> RMSNorm(x') into LDS as the 2-wave gate/up gemv does it
+__device__ __forceinline__ void lb_enter_gu(const LayerArgs& a, uint32_t* box, char* smem) {
+    if (threadIdx.x < 64) spin_until<8>(box + BOX_XREADY, 1, a.f.epoch, a.f.sync + SYNC_TMO, 0x400u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+    rmsnorm_to_lds<128, true>(a.f.xout, a.ln2, a.f.eps, a.f.H, smem);
+}
+
+// a workgroup's rows of an op are stored: drain, meet, one ticket; the last ticket of the episode tells the consumers
+template <bool QKV>
+__device__ __forceinline__ void lb_ticket(const LayerArgs& a) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t old = 0;
+        const int n_o_wg = a.n_wg - a.f.nb_attn;
+        uint32_t* ticket = a.f.sync + (QKV ? SYNC_QKV_ALL : SYNC_O_DONE);
+        const uint32_t want = QKV ? (uint32_t)a.n_wg : (uint32_t)n_o_wg;
+        if (threadIdx.x == 0) old = __hip_atomic_fetch_add(ticket, 1u, O3V_RLX_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == a.f.epoch * want - 1u) {
+            if (QKV) {
+                notify_mailboxes(a.f.sync + SYNC_BOX_ATT, a.f.nb_attn, 0, a.f.epoch);
+            } else {
+                notify_mailboxes(a.f.sync + SYNC_BOX_ATT, a.f.nb_attn, BOX_XREADY, a.f.epoch);
+                notify_mailboxes(a.f.sync + SYNC_BOX_O, n_o_wg, BOX_XREADY, a.f.epoch);
+            }
+        }
+    }
+}
+
+// q/k/v rotary pair of this wave from buffers b0 (row j) and b1 (row j + D/2): bias, rotation, q out / new K,V row (gemv_body's
+// EPI_QKVROPE epilogue), stored write-through
+template <int NS>
+__device__ __forceinline__ void lb_qkv_pair(const LayerArgs& a, const u32x4 (&b0)[NS], const u32x4 (&b1)[NS], int row0, float bias0, float bias1,
+                                            float cs, float sn, const char* vec) {
+    const float acc0 = lb_dot<NS>(b0, vec), acc1 = lb_dot<NS>(b1, vec);
+    if ((threadIdx.x & 63) != 0) return;
+    const RopeArgs& ra = a.f.ra;
+    const int half = ra.D >> 1, head = row0 / ra.D, j = row0 % ra.D;
+    const float v0 = rbf(acc0 + bias0), v1 = rbf(acc1 + bias1);
+    if (head >= ra.Hq + ra.Hkv) {  // v: no rotation
+        bf16_t* dst = ra.vc + ((size_t)(head - ra.Hq - ra.Hkv) * ra.Tmax + ra.slot) * ra.D;
+        gemv_store_bf16<true>(dst + j, f2bf(v0));
+        gemv_store_bf16<true>(dst + j + half, f2bf(v1));
+        return;
+    }
+    const float o0 = __fadd_rn(rbf(__fmul_rn(v0, cs)), rbf(__fmul_rn(-v1, sn)));
+    const float o1 = __fadd_rn(rbf(__fmul_rn(v1, cs)), rbf(__fmul_rn(v0, sn)));
+    bf16_t* dst = head < ra.Hq ? ra.qout + (size_t)head * ra.D : ra.kc + ((size_t)(head - ra.Hq) * ra.Tmax + ra.slot) * ra.D;
+    gemv_store_bf16<true>(dst + j, f2bf(o0));
+    gemv_store_bf16<true>(dst + j + half, f2bf(o1));
+}
+
+template <int NS>
+struct RowPipe {
+    u32x4 b[3][NS];
+    float res[3];  // o_proj rows: the residual, requested with the row
+    SubUnit d[3];
+};
+
+template <int I3, int NS>
+__device__ __forceinline__ void lb_issue(RowPipe<NS>& P, const LayerArgs& a, const SubUnit u) {
+    P.d[I3] = SubUnit{__builtin_amdgcn_readfirstlane(u.kind), __builtin_amdgcn_readfirstlane(u.row)};
+    P.res[I3] = 0.f;
+    if (P.d[I3].kind == SU_NONE) {  // (defined on every path: an old row must not stay live in the compiler's eyes)
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) P.b[I3][s2] = (u32x4){0, 0, 0, 0};
+        return;
+    }
+    if (P.d[I3].kind == SU_O) {
+        lb_load<NS>(P.b[I3], a.f.o_w, P.d[I3].row);
+        P.res[I3] = bf2f(a.f.x[P.d[I3].row]);  // residual: written by an earlier launch
+    } else {
+        lb_load<NS>(P.b[I3], a.gu_w, P.d[I3].row);
+    }
+}
+
+// The row stream of one wave behind its q/k/v pair: [o_proj rows] [gate, up, gate, up, ...], three rows in flight.  `in_o`: the
+// workgroup owns o_proj rows (every wave of it then enters and leaves the o_proj op, also one that owns none).  The ticket of the
+// o_proj op is taken BEFORE the freed buffer is refilled (the loads still in flight are old: the drain costs no latency), the
+// refill goes out before the wait for x'.
+template <int NS>
+__device__ __forceinline__ void lb_stream(RowPipe<NS>& P, const LayerArgs& a, RowEnum& E, bool in_o, uint32_t* box, char* smem) {
+    float gate_acc = 0.f;
+    bool done = false;
+    const int lane = threadIdx.x & 63;
+#define O3V_LB_STEP(I3, NX)                                                                        \
+    if (!done) {                                                                                   \
+        const SubUnit u = P.d[I3];                                                                 \
+        if (u.kind == SU_NONE) {                                                                   \
+            done = true;                                                                           \
+        } else {                                                                                   \
+            if (in_o && u.kind != SU_O) { /* a wave without o_proj rows: it only meets the others */ \
+                lb_ticket<false>(a);                                                               \
+                lb_enter_gu(a, box, smem);                                                         \
+                in_o = false;                                                                      \
+            }                                                                                      \
+            const float acc = lb_dot<NS>(P.b[I3], smem);                                           \
+            if (u.kind == SU_O) {                                                                  \
+                if (lane == 0) {                                                                   \
+                    float v = acc + 0.f; /* no bias (TF:620) */                                    \
+                    v = rbf(v) + P.res[I3];                                                        \
+                    gemv_store_bf16<true>(a.f.xout + u.row, f2bf(v));                              \
+                }                                                                                  \
+                if (P.d[NX].kind != SU_O) { /* this wave's last o_proj row */                      \
+                    lb_ticket<false>(a);                                                           \
+                    lb_issue<I3, NS>(P, a, E.next());                                              \
+                    lb_enter_gu(a, box, smem);                                                     \
+                    in_o = false;                                                                  \
+                } else {                                                                           \
+                    lb_issue<I3, NS>(P, a, E.next());                                              \
+                }                                                                                  \
+            } else {                                                                               \
+                if (u.kind == SU_G) {                                                              \
+                    gate_acc = acc;                                                                \
+                } else if (lane == 0) {                                                            \
+                    const int grow = u.row - 16, no = (grow >> 5) * 16 + (grow & 15);              \
+                    const float g = rbf(gate_acc + 0.f), uu = rbf(acc + 0.f);                      \
+                    a.act[no] = f2bf(rbf(silu_f(g)) * uu);                                         \
+                }                                                                                  \
+                lb_issue<I3, NS>(P, a, E.next());                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    while (!done) {
+        O3V_LB_STEP(2, 0)   // the stream starts in buffer 2: buffers 0 and 1 carried the q/k/v pair
+        O3V_LB_STEP(0, 1)
+        O3V_LB_STEP(1, 2)
+    }
+#undef O3V_LB_STEP
+    if (in_o) {  // (cannot happen: every wave owns gate/up rows; kept so that the workgroup's barriers always pair up)
+        lb_ticket<false>(a);
+        lb_enter_gu(a, box, smem);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 3) void decode_layer_block_kernel(LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // wave-uniform values are told to the compiler as such (readfirstlane): the row descriptors, their pointers and every branch on
+    // them then live in SGPRs / scalar branches instead of per-lane registers and exec masks
+    const int bid = blockIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int Hq = a.f.ra.Hq, Hkv = a.f.ra.Hkv, D = a.f.ra.D, n_rep = Hq / Hkv;
+    const bool attn_wg = bid < a.f.nb_attn;
+    uint32_t* box = attn_wg ? a.f.sync + SYNC_BOX_ATT + (size_t)bid * O3V_SYNC_STRIDE
+                            : a.f.sync + SYNC_BOX_O + (size_t)(bid - a.f.nb_attn) * O3V_SYNC_STRIDE;
+    RowEnum E;
+    E.G = bid * 4 + wave;
+    E.NW = a.n_wg * 4;
+    E.NWo = (a.n_wg - a.f.nb_attn) * 4;
+    E.Go = attn_wg ? -1 : (bid - a.f.nb_attn) * 4 + wave;
+    E.No = a.f.H;
+    E.Pg = a.I;
+    E.k = 0;
+    E.cur = 0;
+    E.phase = 0;
+    RowPipe<NS> P;
+    // ---- t = 0: the q/k/v rotary pair of this wave (at most one: pairs <= waves) into buffers 0 / 1; an o_proj owner also
+    // requests the first row of its stream into buffer 2, and a wave without a pair fills buffers 0 / 1 from its stream as well
+    const int Pq = (Hq + 2 * Hkv) * D / 2, half = D >> 1;
+    const bool has_q = E.G < Pq;
+    const int row0 = has_q ? (E.G / half) * D + (E.G % half) : 0;
+    float bias0 = 0.f, bias1 = 0.f, cs = 1.f, sn = 0.f;
+    lb_issue<0, NS>(P, a, SubUnit{SU_NONE, 0});
+    lb_issue<1, NS>(P, a, SubUnit{SU_NONE, 0});
+    lb_issue<2, NS>(P, a, SubUnit{SU_NONE, 0});
+    if (has_q) {
+        lb_load<NS>(P.b[0], a.f.qkv_w, row0);
+        lb_load<NS>(P.b[1], a.f.qkv_w, row0 + half);
+        if (a.f.qkv_b) {
+            bias0 = bf2f(a.f.qkv_b[row0]);
+            bias1 = bf2f(a.f.qkv_b[row0 + half]);
+        }
+        const size_t ci = (size_t)a.f.ra.cs_off * D + (row0 % D);
+        cs = bf2f(a.f.ra.cosT[ci]);
+        sn = bf2f(a.f.ra.sinT[ci]);
+    }
+    if (!attn_wg) {
+        lb_issue<2, NS>(P, a, E.next());
+        if (!has_q) {
+            lb_issue<0, NS>(P, a, E.next());
+            lb_issue<1, NS>(P, a, E.next());
+        }
+    }
+    rmsnorm_to_lds<256, false>(a.f.x, a.f.ln_w, a.f.eps, a.f.H, smem);
+    if (has_q) lb_qkv_pair<NS>(a, P.b[0], P.b[1], row0, bias0, bias1, cs, sn, smem);
+    lb_ticket<true>(a);  // E1: every workgroup's q / k / v rows are in memory -> the attention items
+    if (!attn_wg) {
+        if (has_q) {
+            lb_issue<0, NS>(P, a, E.next());
+            lb_issue<1, NS>(P, a, E.next());
+        }
+        // o_proj operand: the attention output, once every kv head's merged slices are in memory (E3)
+        if (wave == 0) spin_until<8>(box, Hkv, a.f.epoch, a.f.sync + SYNC_TMO, 0x200u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
+        {
+            const int nch = (Hq * D) >> 3;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.f.att, 0, Hq * D * 2, 0x00020000);
+            for (int c = threadIdx.x; c < nch; c += 256) *reinterpret_cast<u32x4*>(smem + (size_t)c * 16) = load16_sc1(rs, (uint32_t)c * 16);
+        }
+        __syncthreads();
+        lb_stream<NS>(P, a, E, true, box, smem);
+        return;
+    }
+    // ---- attention workgroup: one (kv head, context split) item -- nothing of the row pipeline is live across it -- then its
+    // share of the gate/up rows
+    {
+        const int t = bid, split = t % a.f.nsplit, hk = t / a.f.nsplit;
+        AttnHandoff ho{box,
+                       a.f.sync + SYNC_BOX_ATT + (size_t)hk * a.f.nsplit * O3V_SYNC_STRIDE,
+                       a.f.sync + SYNC_ATT + hk * O3V_SYNC_STRIDE,
+                       a.f.sync + SYNC_ATT2 + hk * O3V_SYNC_STRIDE,
+                       a.f.sync + SYNC_BOX_O,
+                       a.n_wg - a.f.nb_attn,
+                       a.f.epoch,
+                       a.f.sync + SYNC_TMO,
+                       a.f.att};
+#ifdef O3V_STAMPS
+        ho.stamp = nullptr;
+        ho.no_prefetch = false;
+#endif
+        attn_decode_mfma_body<true>(a.f.ra.qout, a.f.ra.kc, a.f.ra.vc, a.f.part_o, a.f.part_ml, a.f.k_lo, a.f.ctx, Hq, Hkv, n_rep,
+                                    (long)a.f.ra.Tmax * D, (long)Hkv * a.f.ra.Tmax * D, a.f.scale_log2e, 0, a.f.nsplit, 0, 1, 0, split,
+                                    a.f.nsplit, hk, 0, smem, ho);
+    }
+    __syncthreads();  // the attention scratch is dead: the operand vector of gate/up goes there
+    RowPipe<NS> P2;
+    lb_issue<2, NS>(P2, a, E.next());
+    lb_issue<0, NS>(P2, a, E.next());
+    lb_issue<1, NS>(P2, a, E.next());
+    lb_enter_gu(a, box, smem);
+    lb_stream<NS>(P2, a, E, false, box, smem);
+}
+
+
 // o_proj row lengths built (steps of 64 chunks): bf16 rows of 1792 (fixtures) / 2048 (3B) / 3584 (7B) / 4096 (8B class) take
 // 4 / 4 / 7 / 8 steps, their fp8 forms 2 / 2 / 4 / 4
 #define O3V_FUSED_SHAPES(X) X(7, 2) X(4, 2) X(8, 2) X(2, 1) X(4, 1)
@@ -346,6 +729,89 @@ extern "C" int o3v_decode_attn_block(void* x, const void* ln_w, float eps, const
     return attn_block_launch(x, ln_w, eps, qkv_w, nullptr, qkv_b, o_w, nullptr, nullptr, nullptr, nullptr, cosT, sinT, q_buf, att_buf,
                              kcache, vcache, part_o, part_ml, k_lo, H, Hq, Hkv, D, slot, Tmax, cs_stride_row, cs_off, nsplit, scale, sync,
                              epoch, stream);
+}
+
+// ---- the persistent layer block (decode_layer_block_kernel): bf16 rows, no q/k norm; head_dim 128, hidden = Hq * D a whole number
+// of 512-element steps (2048: 3B, 3584: 7B), at most one q/k/v rotary pair and two o_proj rows per wave of the resident grid
+template <int NS>
+static int layer_block_capacity() {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_layer_block_kernel<NS>, 256, ATTN_LDS) != hipSuccess) return 0;
+    if (per_cu < 3) return 0;
+    return 3 * prop.multiProcessorCount;  // the grid: three workgroups per CU, all resident
+}
+
+extern "C" int o3v_decode_layer_block(void* x, const void* ln1, float eps, const void* qkv_w, const void* qkv_b, const void* o_w,
+                                      const void* ln2, const void* gu_w, void* act, const void* cosT, const void* sinT, void* q_buf,
+                                      void* att_buf, void* kcache, void* vcache, float* part_o, float* part_ml, const int* k_lo, int H,
+                                      int I, int Hq, int Hkv, int D, int slot, int Tmax, int cs_stride_row, int cs_off, int nsplit,
+                                      float scale, uint32_t* sync, uint32_t epoch, hipStream_t stream) {
+    if (!x || !ln1 || !qkv_w || !o_w || !ln2 || !gu_w || !act || !cosT || !sinT || !q_buf || !att_buf || !kcache || !vcache || !part_o ||
+        !part_ml || !sync || epoch == 0 || slot < 0 || slot >= Tmax || H <= 0 || I <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || nsplit <= 0 ||
+        nsplit > 64)
+        return O3V_ERR_ARG;
+    const int n_rep = Hq / Hkv, QD = Hq * D, NQKV = (Hq + 2 * Hkv) * D;
+    if (D != 128 || Hkv > 8 || n_rep > NREP_MAX || (H % 512) || QD != H || (I & 15)) return O3V_ERR_SHAPE;
+    const int ns = H / 512;
+    int n_wg = 0;
+    if (ns == 4) {
+        static const int cap = layer_block_capacity<4>();
+        n_wg = cap;
+    } else if (ns == 7) {
+        static const int cap = layer_block_capacity<7>();
+        n_wg = cap;
+    } else {
+        return O3V_ERR_SHAPE;
+    }
+    const int nb_attn = nsplit * Hkv;
+    if (n_wg <= 0 || nb_attn > 512 || nb_attn >= n_wg) return O3V_ERR_SHAPE;
+    const int n_o_wg = n_wg - nb_attn;
+    if (n_o_wg > 1024 || NQKV / 2 > n_wg * 4 || H > 2 * n_o_wg * 4) return O3V_ERR_SHAPE;  // one rotary pair, two o_proj rows per wave
+    LayerArgs a;
+    a.f.qkv_s = nullptr;
+    a.f.o_s = nullptr;
+    a.f.x = (const bf16_t*)x;
+    a.f.ln_w = (const bf16_t*)ln1;
+    a.f.qkv_w = (const bf16_t*)qkv_w;
+    a.f.qkv_b = (const bf16_t*)qkv_b;
+    a.f.o_w = (const bf16_t*)o_w;
+    a.f.att = (bf16_t*)att_buf;
+    a.f.xout = (bf16_t*)x;
+    a.f.part_o = part_o;
+    a.f.part_ml = part_ml;
+    a.f.k_lo = k_lo;
+    a.f.sync = sync;
+    a.f.epoch = epoch;
+    a.f.ra = RopeArgs{(const bf16_t*)cosT, (const bf16_t*)sinT, (bf16_t*)q_buf, (bf16_t*)kcache, (bf16_t*)vcache,
+                      slot, Hq, Hkv, D, Tmax, cs_stride_row, cs_off};
+    a.f.ra_qkv = a.f.ra;
+    a.f.qk = QkNormRef{};
+    a.f.eps = eps;
+    a.f.scale_log2e = scale * 1.4426950408889634f;
+    a.f.H = H;
+    a.f.ctx = slot + 1;
+    a.f.nsplit = nsplit;
+    a.f.nb_qkv = 0;
+    a.f.nb_attn = nb_attn;
+    a.f.nb_o = 0;
+#ifdef O3V_STAMPS
+    a.f.stamps = nullptr;
+    a.f.knob = 0;
+#endif
+    a.ln2 = (const bf16_t*)ln2;
+    a.gu_w = (const bf16_t*)gu_w;
+    a.act = (bf16_t*)act;
+    a.I = I;
+    a.n_wg = n_wg;
+    const dim3 grid(n_wg), block(256);
+    if (ns == 4)
+        O3V_KLAUNCH((decode_layer_block_kernel<4>), grid, block, ATTN_LDS, stream, a);
+    else
+        O3V_KLAUNCH((decode_layer_block_kernel<7>), grid, block, ATTN_LDS, stream, a);
+    O3V_CHECK_LAUNCH();
+    return O3V_OK;
 }
 
 // the same with fp8 (OCP e4m3fn) rows + per-row scales for the two projections (o3v_linear_decode_fp8's weight format)

@@ -70,6 +70,7 @@ class O3VEngine:
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
         self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
+        self.layer_block = os.environ.get("O3V_LAYER_BLOCK", "1") != "0"           # A/B switch for the persistent layer block
         # video rope arithmetic (indexing.rope_index): "tf5" = transformers 5.15 (goldens G5b / G14 / G15), "pinned" = the
         # libraries the reference installs (transformers @336dc69d, vllm 0.7.2).  The facades choose; images do not depend on it.
         self.position_mode = "tf5"
@@ -511,6 +512,7 @@ class O3VEngine:
                               rows_per_prompt=G if shared_prompt else 0)
         stats = (C.c_longlong * 4)(0, 0, 0, 0)      # decode forwards, launches in their layer loops, fused / stand-alone attention halves
         st.host_stats = C.cast(stats, C.c_void_p)
+        st.flags = 1 if self.layer_block else 0
         tm["kv_cache_bytes"] = int((kc.numel() + vc.numel() + (kc0.numel() + vc0.numel() if shared_prompt else 0)) * 2)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0

@@ -1286,3 +1286,79 @@ def test_decode_attn_block_fp8_equals_three_launches(dev, Hq, Hkv, H, ctx, Tmax,
         assert int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item()) == 0
         assert torch.equal(q2.view(torch.int16), q1.view(torch.int16)) and torch.equal(k2.view(torch.int16), k1.view(torch.int16))
         assert torch.equal(att2.view(torch.int16), att1.view(torch.int16)) and torch.equal(x2.view(torch.int16), x1.view(torch.int16))
+
+
+@pytest.mark.parametrize("Hq,Hkv,H,I,ctx,Tmax,nsplit,pad", [
+    (28, 4, 3584, 18944, 4491, 5002, 37, 0),     # 7B, first decode step of the bench prompt
+    (28, 4, 3584, 18944, 5002, 5002, 40, 37),    # last slot of the cache, left-padded prompt
+    (16, 2, 2048, 11008, 1500, 1732, 14, 0),     # 3B dims (n_rep 8)
+    (16, 2, 2048, 2752, 40, 64, 1, 0),           # fixture dims (tests/fixture_models.py tied3b), one split
+    (28, 4, 3584, 18944, 97, 20480, 64, 3),      # few keys against 64 splits: most attention items hold no key at all
+    (28, 4, 3584, 18944, 1, 64, 1, 0),           # one key (the token itself)
+])
+def test_decode_layer_block_equals_stand_alone_launches(dev, Hq, Hkv, H, I, ctx, Tmax, nsplit, pad):
+    """o3v_decode_layer_block (ONE persistent launch: q/k/v -> attention -> merge -> o_proj -> RMSNorm -> gate/up + SwiGLU, every wave
+    streaming its own weight rows across the in-launch hand-offs) == o3v_gemv_norm_qkv_rope + o3v_attn_decode + o3v_linear_decode(o_proj,
+    RESIDUAL) + o3v_linear_decode(gate/up, fused RMSNorm, SWIGLU) BIT FOR BIT: residual stream, q, attention output, the appended K/V
+    row, the SwiGLU vector.  Three epochs on one sync buffer with new inputs each time."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import pack_gate_up
+    D, Tnew, step = 128, 7, 3
+    slot = ctx - 1
+    g = torch.Generator().manual_seed(Hq * 1000 + ctx + I)
+    N, QD = (Hq + 2 * Hkv) * D, Hq * D
+    nw1 = (1 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    nw2 = (1 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    wqkv = (torch.randn(N, H, generator=g) / math.sqrt(H)).to(BF).to(dev)
+    bqkv = (0.5 * torch.randn(N, generator=g)).to(BF).to(dev)
+    wo = (torch.randn(H, QD, generator=g) / math.sqrt(QD)).to(BF).to(dev)
+    wgu = pack_gate_up((torch.randn(I, H, generator=g) / math.sqrt(H)).to(BF), (torch.randn(I, H, generator=g) / math.sqrt(H)).to(BF), I).to(dev)
+    ang = torch.rand(1, Tnew, D // 2, generator=g) * 30
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(BF).to(dev).contiguous()
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(BF).to(dev).contiguous()
+    kc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    vc0 = torch.randn(1, Hkv, Tmax, D, generator=g).to(BF).to(dev)
+    kc0[:, :, slot] = float("nan")
+    vc0[:, :, slot] = float("nan")
+    k_lo = torch.tensor([pad], dtype=torch.int32, device=dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
+    part_o = torch.empty(Hq * 64 * D, dtype=torch.float32, device=dev)
+    part_ml = torch.empty(Hq * 64 * 2, dtype=torch.float32, device=dev)
+    q2, att2 = torch.zeros(1, Hq, D, dtype=BF, device=dev), torch.zeros(1, Hq, D, dtype=BF, device=dev)
+    k2, v2 = kc0.clone(), vc0.clone()
+    act2 = torch.zeros(1, I, dtype=BF, device=dev)
+    for rep in range(3):
+        x0 = (torch.randn(1, H, generator=g) * 2).to(BF).to(dev)
+        x1 = x0.clone()
+        q1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        k1, v1 = kc0.clone(), vc0.clone()
+        att1 = torch.zeros(1, Hq, D, dtype=BF, device=dev)
+        act1 = torch.zeros(1, I, dtype=BF, device=dev)
+        po1, pm1 = torch.empty_like(part_o), torch.empty_like(part_ml)
+        _lib.call("o3v_gemv_norm_qkv_rope", P(x1), P(nw1), 1e-6, P(wqkv), None, P(bqkv), 1, H, H, P(cos), P(sin), P(q1), P(k1), P(v1),
+                  slot, Hq, Hkv, D, Tmax, Tnew, step, st)
+        _lib.call("o3v_attn_decode", P(q1), P(k1), P(v1), P(att1), P(po1), P(pm1), P(k_lo), 1, Hq, Hkv, D, ctx, Tmax, nsplit, scale, st)
+        _lib.call("o3v_linear_decode", P(att1), None, 0.0, P(wo), None, None, P(x1), P(x1), 1, H, QD, QD, H, H, _lib.EPI_RESIDUAL, st)
+        _lib.call("o3v_linear_decode", P(x1), P(nw2), 1e-6, P(wgu), None, None, None, P(act1), 1, 2 * I, H, H, I, 0, _lib.EPI_SWIGLU, st)
+        x2 = x0.clone()
+        k2[:, :, slot] = float("nan")
+        v2[:, :, slot] = float("nan")
+        act2.zero_()
+        rc = lib.o3v_decode_layer_block(P(x2), P(nw1), 1e-6, P(wqkv), P(bqkv), P(wo), P(nw2), P(wgu), P(act2), P(cos), P(sin), P(q2), P(att2),
+                                        P(k2), P(v2), P(part_o), P(part_ml), P(k_lo), H, I, Hq, Hkv, D, slot, Tmax, Tnew, step, nsplit, scale,
+                                        P(sync), rep + 1, st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        tmo = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+        assert tmo == 0, f"an in-launch wait timed out (code {tmo:#x})"
+        assert not torch.isnan(x1.float()).any() and not torch.isnan(act1.float()).any()
+        assert torch.equal(q2.view(torch.int16), q1.view(torch.int16))
+        assert torch.equal(k2.view(torch.int16), k1.view(torch.int16)) and torch.equal(v2.view(torch.int16), v1.view(torch.int16))
+        assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
+        assert torch.equal(act2.view(torch.int16), act1.view(torch.int16))
