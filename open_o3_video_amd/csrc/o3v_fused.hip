@@ -247,69 +247,38 @@ struct LayerArgs {
     int I, n_wg;
 };
 
-// rows a wave consumes after its q/k/v pair, in order: its o_proj rows (at most two), then its (gate, up) pairs
-enum { SU_NONE = 0, SU_O = 1, SU_G = 2, SU_U = 3 };
-struct SubUnit {
-    int kind, row;
-};
-struct RowEnum {
-    int G, NW, Go, NWo, No, Pg, k, cur, phase;  // phase 0: o_proj rows, 1: gate row next, 2: up row next, 3: done
-    __device__ __forceinline__ int gu_pair(int kk) const {
+// The (gate, up) rows of wave G of NW: output column (pair) kk * NW + G in round kk; the last, partial round goes to every
+// stride-th wave, so that no workgroup gets a whole extra round.  Row 2 kk is the pair's gate row, 2 kk + 1 its up row (16-row
+// interleaved weight: gate row of column p at (p >> 4) * 32 + (p & 15), up row + 16).
+struct GuRows {
+    int G, NW, Pg;
+    __device__ __forceinline__ int pairs() const {
         const int full = Pg / NW, rem = Pg - full * NW;
-        if (kk < full) return kk * NW + G;
-        if (kk == full && rem > 0) {  // the last, partial round goes to every stride-th wave: no workgroup gets a whole extra round
-            const int stride = NW / rem;
-            if (G % stride == 0 && G / stride < rem) return full * NW + G / stride;
-        }
-        return -1;
+        if (rem == 0) return full;
+        const int stride = NW / rem;
+        return full + ((G % stride == 0 && G / stride < rem) ? 1 : 0);
     }
-    __device__ __forceinline__ SubUnit next() {
-        if (phase == 0) {
-            const int r = Go >= 0 ? Go + k * NWo : No;
-            if (r < No) {
-                ++k;
-                return SubUnit{SU_O, r};
-            }
-            phase = 1;
-            k = 0;
-        }
-        if (phase == 1) {
-            const int p = gu_pair(k);
-            if (p < 0) {
-                phase = 3;
-                return SubUnit{SU_NONE, 0};
-            }
-            cur = (p >> 4) * 32 + (p & 15);  // gate row of output column p in the 16-row interleaved weight; its up row is + 16
-            phase = 2;
-            return SubUnit{SU_G, cur};
-        }
-        if (phase == 2) {
-            phase = 1;
-            ++k;
-            return SubUnit{SU_U, cur + 16};
-        }
-        return SubUnit{SU_NONE, 0};
+    __device__ __forceinline__ int row(int k) const {
+        const int kk = k >> 1, full = Pg / NW;
+        const int p = kk < full ? kk * NW + G : full * NW + G / (NW / (Pg - full * NW));
+        return (p >> 4) * 32 + (p & 15) + (k & 1) * 16;
     }
 };
 
+// workgroup barrier that orders LDS only: __syncthreads() carries a fence, and the compiler drains vmcnt(0) for it -- i.e. it would
+// wait for every weight row the waves keep in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // RMSNorm of a K-vector into LDS exactly as gemv_body's NORM prologue does it for M = 1 with NT threads (NT / 64 waves): the
-// per-thread fmaf chains, the wave sums and the order in which the wave sums are added.  SC1: x was produced in this launch.
-template <int NT, bool SC1>
-__device__ __forceinline__ void rmsnorm_to_lds(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, float eps, int K, char* smem) {
-    constexpr int XC = (512 + NT - 1) / NT, NWN = NT / 64;
+// per-thread fmaf chains, the wave sums and the order in which the wave sums are added.  The caller has loaded the x chunks
+// (thread t: chunks t + i NT, zeros past the row) and the matching norm-weight chunks -- it decides when those loads are issued
+// relative to the weight rows.
+template <int NT, int XC>
+__device__ __forceinline__ void norm_finish(const u32x4 (&xr)[XC], const u32x4 (&wn)[XC], float eps, int K, char* smem) {
+    constexpr int NWN = NT / 64;
     const int nxc = K >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* red = reinterpret_cast<float*>(smem + LB_RED);
-    u32x4 xr[XC];  // (the norm weights are fetched at store time: this code runs with a wave's weight rows live in registers)
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, K * 2, 0x00020000);
     if (tid < NT) {
-#pragma unroll
-        for (int i = 0; i < XC; ++i) {
-            const int c = tid + i * NT;
-            if (SC1)
-                xr[i] = load16_sc1(xrs, c < nxc ? (uint32_t)c * 16 : O3V_OOB);
-            else
-                xr[i] = c < nxc ? *reinterpret_cast<const u32x4*>(x + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
-        }
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < XC; ++i)
@@ -321,7 +290,7 @@ __device__ __forceinline__ void rmsnorm_to_lds(const bf16_t* __restrict__ x, con
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < NT) {
         float t = red[0];
 #pragma unroll
@@ -331,26 +300,60 @@ __device__ __forceinline__ void rmsnorm_to_lds(const bf16_t* __restrict__ x, con
         for (int i = 0; i < XC; ++i) {
             const int c = tid + i * NT;
             if (c < nxc) {
-                const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
                 u32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    o[j] = pack_bf2(bf_lo(wn[j]) * rbf(bf_lo(xr[i][j]) * rstd), bf_hi(wn[j]) * rbf(bf_hi(xr[i][j]) * rstd));
+                    o[j] = pack_bf2(bf_lo(wn[i][j]) * rbf(bf_lo(xr[i][j]) * rstd), bf_hi(wn[i][j]) * rbf(bf_hi(xr[i][j]) * rstd));
                 *reinterpret_cast<u32x4*>(smem + (size_t)c * 16) = o;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
-// one weight row of NS whole steps (K = 512 NS) in registers: requested with non-temporal loads, multiplied with the operand
-// vector in LDS in gemv_body's order (chunk lane + 64 i, i ascending), then the wave sum
+// loads the compiler does not track (see lb_load): 16 bytes from a per-lane address, a bf16 scalar from a wave-uniform address
+__device__ __forceinline__ u32x4 asm_load16(const void* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t asm_load_bf16(const bf16_t* p) {
+    uint32_t v;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// The row loads are written as asm and waited for by hand.  With compiler-visible loads the waitcnt pass loses the count of
+// outstanding loads at the (wave-uniform) branches of the stream loop and waits for vmcnt(0..6) before it touches the OLDEST of the
+// three rows in flight -- i.e. for all three -- which leaves one row in flight per wave instead of three (measured: the block was
+// 14 us per layer slower than the launches it replaces).  Loads return in order, so "at most NS * (rows requested after this one)
+// operations outstanding" means this row has landed; stores or other loads issued in between only make that wait stricter.
 template <int NS>
 __device__ __forceinline__ void lb_load(u32x4 (&b)[NS], const bf16_t* __restrict__ W, int row) {
-    const u32x4* wp = reinterpret_cast<const u32x4*>(W + (size_t)row * (NS * 512)) + (threadIdx.x & 63);
+    const char* base = reinterpret_cast<const char*>(W) + (size_t)row * (NS * 1024);  // wave-uniform: an SGPR pair
+    const uint32_t v0 = (uint32_t)(threadIdx.x & 63) * 16u, v1 = v0 + 4096u;           // the immediate offset reaches 4095
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) b[s2] = __builtin_nontemporal_load(wp + s2 * 64);
+    for (int s2 = 0; s2 < NS; ++s2) {
+        if (s2 < 4)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(b[s2]) : "v"(v0), "s"(base), "n"(s2 * 1024) : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(b[s2]) : "v"(v1), "s"(base), "n"((s2 - 4) * 1024) : "memory");
+    }
 }
+// wait until at most NS * `younger` vector-memory operations are outstanding; the row's registers pass through the asm so that no
+// use of them can be scheduled above the wait
+template <int NS>
+__device__ __forceinline__ void lb_wait(u32x4 (&b)[NS], int younger) {
+    if (younger >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
+    else if (younger == 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(b[s2]));
+}
+__device__ __forceinline__ void asm_tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
 template <int NS>
 __device__ __forceinline__ float lb_dot(const u32x4 (&b)[NS], const char* vec) {
     const char* vp = vec + (size_t)(threadIdx.x & 63) * 16;
@@ -364,12 +367,25 @@ __device__ __forceinline__ float lb_dot(const u32x4 (&b)[NS], const char* vec) {
     return wave_sum(acc);
 }
 
-// the residual stream after o_proj is complete -> RMSNorm(x') into LDS as the 2-wave gate/up gemv does it
+// the residual stream after o_proj is complete -> RMSNorm(x') into LDS as the 2-wave gate/up gemv does it (threads 0..127).  The
+// polls and the x' chunks are ordinary loads: they return behind the row this wave requested last, which has had the whole
+// hand-off to land.
 __device__ __forceinline__ void lb_enter_gu(const LayerArgs& a, uint32_t* box, char* smem) {
     if (threadIdx.x < 64) spin_until<8>(box + BOX_XREADY, 1, a.f.epoch, a.f.sync + SYNC_TMO, 0x400u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __syncthreads();
-    rmsnorm_to_lds<128, true>(a.f.xout, a.ln2, a.f.eps, a.f.H, smem);
+    lds_barrier();
+    constexpr int XC = 4;
+    const int nxc = a.f.H >> 3, tid = threadIdx.x;
+    u32x4 xr[XC], wn[XC];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.f.xout, 0, a.f.H * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * 128;
+        const bool in = tid < 128 && c < nxc;
+        xr[i] = load16_sc1(xrs, in ? (uint32_t)c * 16 : O3V_OOB);
+        wn[i] = in ? *reinterpret_cast<const u32x4*>(a.ln2 + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+    }
+    norm_finish<128, XC>(xr, wn, a.f.eps, a.f.H, smem);
 }
 
 // a workgroup's rows of an op are stored: drain, meet, one ticket; the last ticket of the episode tells the consumers
@@ -418,160 +434,219 @@ __device__ __forceinline__ void lb_qkv_pair(const LayerArgs& a, const u32x4 (&b0
     gemv_store_bf16<true>(dst + j + half, f2bf(o1));
 }
 
+// The gate/up rows of one wave, three in flight: row k lives in buffer (k + 1) % 3 (buffer 1 first: buffers 2 and 0 carry the
+// wave's o_proj rows before).  Nothing but the row loads (asm), the LDS reads, the dot products and the SwiGLU store is in this
+// loop: no hand-off, no compiler-visible load -- so no wait but the hand-written one.  `y0` / `y1`: rows known to be younger than
+// row 0 / row 1 when the loop starts (then 2).
 template <int NS>
-struct RowPipe {
-    u32x4 b[3][NS];
-    float res[3];  // o_proj rows: the residual, requested with the row
-    SubUnit d[3];
-};
-
-template <int I3, int NS>
-__device__ __forceinline__ void lb_issue(RowPipe<NS>& P, const LayerArgs& a, const SubUnit u) {
-    P.d[I3] = SubUnit{__builtin_amdgcn_readfirstlane(u.kind), __builtin_amdgcn_readfirstlane(u.row)};
-    P.res[I3] = 0.f;
-    if (P.d[I3].kind == SU_NONE) {  // (defined on every path: an old row must not stay live in the compiler's eyes)
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) P.b[I3][s2] = (u32x4){0, 0, 0, 0};
-        return;
-    }
-    if (P.d[I3].kind == SU_O) {
-        lb_load<NS>(P.b[I3], a.f.o_w, P.d[I3].row);
-        P.res[I3] = bf2f(a.f.x[P.d[I3].row]);  // residual: written by an earlier launch
-    } else {
-        lb_load<NS>(P.b[I3], a.gu_w, P.d[I3].row);
-    }
-}
-
-// The row stream of one wave behind its q/k/v pair: [o_proj rows] [gate, up, gate, up, ...], three rows in flight.  `in_o`: the
-// workgroup owns o_proj rows (every wave of it then enters and leaves the o_proj op, also one that owns none).  The ticket of the
-// o_proj op is taken BEFORE the freed buffer is refilled (the loads still in flight are old: the drain costs no latency), the
-// refill goes out before the wait for x'.
-template <int NS>
-__device__ __forceinline__ void lb_stream(RowPipe<NS>& P, const LayerArgs& a, RowEnum& E, bool in_o, uint32_t* box, char* smem) {
-    float gate_acc = 0.f;
-    bool done = false;
+__device__ __forceinline__ void lb_gu_loop(u32x4 (&b0)[NS], u32x4 (&b1)[NS], u32x4 (&b2)[NS], const LayerArgs& a, const GuRows& R,
+                                           const int n_rows, const int y0, const int y1, const char* smem) {
     const int lane = threadIdx.x & 63;
-#define O3V_LB_STEP(I3, NX)                                                                        \
-    if (!done) {                                                                                   \
-        const SubUnit u = P.d[I3];                                                                 \
-        if (u.kind == SU_NONE) {                                                                   \
-            done = true;                                                                           \
-        } else {                                                                                   \
-            if (in_o && u.kind != SU_O) { /* a wave without o_proj rows: it only meets the others */ \
-                lb_ticket<false>(a);                                                               \
-                lb_enter_gu(a, box, smem);                                                         \
-                in_o = false;                                                                      \
-            }                                                                                      \
-            const float acc = lb_dot<NS>(P.b[I3], smem);                                           \
-            if (u.kind == SU_O) {                                                                  \
-                if (lane == 0) {                                                                   \
-                    float v = acc + 0.f; /* no bias (TF:620) */                                    \
-                    v = rbf(v) + P.res[I3];                                                        \
-                    gemv_store_bf16<true>(a.f.xout + u.row, f2bf(v));                              \
-                }                                                                                  \
-                if (P.d[NX].kind != SU_O) { /* this wave's last o_proj row */                      \
-                    lb_ticket<false>(a);                                                           \
-                    lb_issue<I3, NS>(P, a, E.next());                                              \
-                    lb_enter_gu(a, box, smem);                                                     \
-                    in_o = false;                                                                  \
-                } else {                                                                           \
-                    lb_issue<I3, NS>(P, a, E.next());                                              \
-                }                                                                                  \
-            } else {                                                                               \
-                if (u.kind == SU_G) {                                                              \
-                    gate_acc = acc;                                                                \
-                } else if (lane == 0) {                                                            \
-                    const int grow = u.row - 16, no = (grow >> 5) * 16 + (grow & 15);              \
-                    const float g = rbf(gate_acc + 0.f), uu = rbf(acc + 0.f);                      \
-                    a.act[no] = f2bf(rbf(silu_f(g)) * uu);                                         \
-                }                                                                                  \
-                lb_issue<I3, NS>(P, a, E.next());                                                  \
-            }                                                                                      \
-        }                                                                                          \
+    float gate_acc = 0.f;
+    int k = 0;
+#define O3V_GU_STEP(BUF, GATE)                                                                  \
+    {                                                                                           \
+        const int left = n_rows - 1 - k;                                                        \
+        int y = k == 0 ? y0 : (k == 1 ? y1 : 2);                                                \
+        y = y < left ? y : left;                                                                \
+        lb_wait<NS>(BUF, y);                                                                    \
+        const float acc = lb_dot<NS>(BUF, smem);                                                \
+        if (GATE) {                                                                             \
+            gate_acc = acc;                                                                     \
+        } else if (lane == 0) {                                                                 \
+            const int grow = R.row(k) - 16, no = (grow >> 5) * 16 + (grow & 15);                \
+            const float g = rbf(gate_acc + 0.f), uu = rbf(acc + 0.f);                           \
+            a.act[no] = f2bf(rbf(silu_f(g)) * uu);                                              \
+        }                                                                                       \
+        if (k + 3 < n_rows) lb_load<NS>(BUF, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(k + 3))); \
+        ++k;                                                                                    \
     }
-    while (!done) {
-        O3V_LB_STEP(2, 0)   // the stream starts in buffer 2: buffers 0 and 1 carried the q/k/v pair
-        O3V_LB_STEP(0, 1)
-        O3V_LB_STEP(1, 2)
+    while (k < n_rows) {  // n_rows is even: a (gate, up) pair is never split by the loop's exit
+        O3V_GU_STEP(b1, true)
+        O3V_GU_STEP(b2, false)
+        if (k >= n_rows) break;
+        O3V_GU_STEP(b0, true)
+        O3V_GU_STEP(b1, false)
+        if (k >= n_rows) break;
+        O3V_GU_STEP(b2, true)
+        O3V_GU_STEP(b0, false)
     }
-#undef O3V_LB_STEP
-    if (in_o) {  // (cannot happen: every wave owns gate/up rows; kept so that the workgroup's barriers always pair up)
-        lb_ticket<false>(a);
-        lb_enter_gu(a, box, smem);
-    }
+#undef O3V_GU_STEP
 }
+
+#ifdef O3V_STAMPS
+#define O3V_LSTAMP(i)                                                                                              \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && a.f.stamps) a.f.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define O3V_LSTAMP(i) \
+    do {              \
+    } while (0)
+#endif
 
 template <int NS>
 __global__ __launch_bounds__(256, 3) void decode_layer_block_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // wave-uniform values are told to the compiler as such (readfirstlane): the row descriptors, their pointers and every branch on
-    // them then live in SGPRs / scalar branches instead of per-lane registers and exec masks
-    const int bid = blockIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    O3V_LSTAMP(0);
+    // wave-uniform values are told to the compiler as such (readfirstlane): row numbers, their pointers and every branch on them
+    // then live in SGPRs / scalar branches instead of per-lane registers and exec masks
+    const int bid = blockIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int Hq = a.f.ra.Hq, Hkv = a.f.ra.Hkv, D = a.f.ra.D, n_rep = Hq / Hkv;
     const bool attn_wg = bid < a.f.nb_attn;
     uint32_t* box = attn_wg ? a.f.sync + SYNC_BOX_ATT + (size_t)bid * O3V_SYNC_STRIDE
                             : a.f.sync + SYNC_BOX_O + (size_t)(bid - a.f.nb_attn) * O3V_SYNC_STRIDE;
-    RowEnum E;
-    E.G = bid * 4 + wave;
-    E.NW = a.n_wg * 4;
-    E.NWo = (a.n_wg - a.f.nb_attn) * 4;
-    E.Go = attn_wg ? -1 : (bid - a.f.nb_attn) * 4 + wave;
-    E.No = a.f.H;
-    E.Pg = a.I;
-    E.k = 0;
-    E.cur = 0;
-    E.phase = 0;
-    RowPipe<NS> P;
-    // ---- t = 0: the q/k/v rotary pair of this wave (at most one: pairs <= waves) into buffers 0 / 1; an o_proj owner also
-    // requests the first row of its stream into buffer 2, and a wave without a pair fills buffers 0 / 1 from its stream as well
+    const int G = bid * 4 + wave, NW = a.n_wg * 4, NWo = (a.n_wg - a.f.nb_attn) * 4;
+    const GuRows R{G, NW, a.I};
+    const int n_rows = 2 * R.pairs();  // >= 6 (the launcher checks I >= 3 * NW)
+    // this wave's o_proj rows (none in an attention workgroup): Go, Go + NWo
+    const int Go = attn_wg ? a.f.H : (bid - a.f.nb_attn) * 4 + wave;
+    const int n_o = Go >= a.f.H ? 0 : (Go + NWo < a.f.H ? 2 : 1);
+    u32x4 b0[NS], b1[NS], b2[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) b0[s2] = b1[s2] = b2[s2] = (u32x4){0, 0, 0, 0};
+    uint32_t res0 = 0, res1 = 0;  // residuals of the o_proj rows (raw bf16)
+    // ---- t = 0.  Every load of this phase is issued and waited for by hand (see lb_load), oldest first:
+    //   x chunks + norm-weight chunks of the RMSNorm (2 + 2 per thread), the epilogue scalars of the q/k/v pair (bias, cos, sin),
+    //   the pair's two weight rows -- then the sum of squares, and only then the first rows of the wave's stream (they have the
+    //   whole attention chain to land; the pair is on the critical path).
     const int Pq = (Hq + 2 * Hkv) * D / 2, half = D >> 1;
-    const bool has_q = E.G < Pq;
-    const int row0 = has_q ? (E.G / half) * D + (E.G % half) : 0;
-    float bias0 = 0.f, bias1 = 0.f, cs = 1.f, sn = 0.f;
-    lb_issue<0, NS>(P, a, SubUnit{SU_NONE, 0});
-    lb_issue<1, NS>(P, a, SubUnit{SU_NONE, 0});
-    lb_issue<2, NS>(P, a, SubUnit{SU_NONE, 0});
+    const bool has_q = G < Pq;  // uniform per workgroup: Pq % 4 == 0 (the launcher checks)
+    const int row0 = has_q ? (G / half) * D + (G % half) : 0;
+    constexpr int XCQ = 2;
+    u32x4 xr[XCQ], wn[XCQ];
+    {
+        const int nxc = a.f.H >> 3, tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < XCQ; ++i) {
+            const int c = tid + i * 256;
+            xr[i] = asm_load16(a.f.x + (size_t)(c < nxc ? c : 0) * 8);
+            wn[i] = asm_load16(a.f.ln_w + (size_t)(c < nxc ? c : 0) * 8);
+        }
+    }
+    uint32_t bias0 = 0, bias1 = 0, cs = 0x3f80u, sn = 0;  // raw bf16; cos = 1, sin = 0
     if (has_q) {
-        lb_load<NS>(P.b[0], a.f.qkv_w, row0);
-        lb_load<NS>(P.b[1], a.f.qkv_w, row0 + half);
         if (a.f.qkv_b) {
-            bias0 = bf2f(a.f.qkv_b[row0]);
-            bias1 = bf2f(a.f.qkv_b[row0 + half]);
+            bias0 = asm_load_bf16(a.f.qkv_b + row0);
+            bias1 = asm_load_bf16(a.f.qkv_b + row0 + half);
         }
         const size_t ci = (size_t)a.f.ra.cs_off * D + (row0 % D);
-        cs = bf2f(a.f.ra.cosT[ci]);
-        sn = bf2f(a.f.ra.sinT[ci]);
+        cs = asm_load_bf16(a.f.ra.cosT + ci);
+        sn = asm_load_bf16(a.f.ra.sinT + ci);
+        // A CU's vector-memory pipeline serves its waves' requests in arrival order: the few KB of x / norm weights that the OTHER
+        // workgroups of this CU are about to ask for must not queue behind this workgroup's 56 KiB of rows (measured: x landed after
+        // 4.6 us in the median, 13 us at worst, instead of 1.8).  All workgroups start within 0.3 us: half a microsecond of sleep.
+        __builtin_amdgcn_s_sleep(20);
+        lb_load<NS>(b0, a.f.qkv_w, row0);
+        lb_load<NS>(b1, a.f.qkv_w, row0 + half);
     }
-    if (!attn_wg) {
-        lb_issue<2, NS>(P, a, E.next());
-        if (!has_q) {
-            lb_issue<0, NS>(P, a, E.next());
-            lb_issue<1, NS>(P, a, E.next());
+    // x / norm weights have landed once at most the younger operations are outstanding: the pair's 2 NS rows (its scalars, older
+    // than the rows, are then there as well)
+    if (has_q)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < XCQ; ++i) {
+        asm volatile("" : "+v"(xr[i]), "+v"(wn[i]));
+        if ((int)threadIdx.x + i * 256 >= (a.f.H >> 3)) {
+            xr[i] = (u32x4){0, 0, 0, 0};
+            wn[i] = (u32x4){0, 0, 0, 0};
         }
     }
-    rmsnorm_to_lds<256, false>(a.f.x, a.f.ln_w, a.f.eps, a.f.H, smem);
-    if (has_q) lb_qkv_pair<NS>(a, P.b[0], P.b[1], row0, bias0, bias1, cs, sn, smem);
-    lb_ticket<true>(a);  // E1: every workgroup's q / k / v rows are in memory -> the attention items
-    if (!attn_wg) {
-        if (has_q) {
-            lb_issue<0, NS>(P, a, E.next());
-            lb_issue<1, NS>(P, a, E.next());
+    O3V_LSTAMP(1);
+    norm_finish<256, XCQ>(xr, wn, a.f.eps, a.f.H, smem);
+    if (has_q) {
+        lb_wait<NS>(b0, 1);  // the pair's second row is younger
+        lb_wait<NS>(b1, 0);
+        asm_tie(bias0);
+        asm_tie(bias1);
+        asm_tie(cs);
+        asm_tie(sn);
+        lb_qkv_pair<NS>(a, b0, b1, row0, bf2f((bf16_t)bias0), bf2f((bf16_t)bias1), bf2f((bf16_t)cs), bf2f((bf16_t)sn), smem);
+    }
+    O3V_LSTAMP(2);
+    // E1, per kv head as in the role-per-workgroup block: the 16 workgroups of a q / k / v head (64 rotary pairs) take tickets on the
+    // head group's line; the last of its (n_rep + 2) * 16 tickets tells that kv head's attention items
+    if (has_q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int head = (bid * 4) / half;
+            const int g = head < Hq ? head / n_rep : (head - Hq) % Hkv;
+            uint32_t old = 0;
+            if (threadIdx.x == 0) old = __hip_atomic_fetch_add(a.f.sync + SYNC_QKV + g * O3V_SYNC_STRIDE, 1u, O3V_RLX_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == a.f.epoch * (uint32_t)((n_rep + 2) * (D >> 3)) - 1u)
+                notify_mailboxes(a.f.sync + SYNC_BOX_ATT + (size_t)g * a.f.nsplit * O3V_SYNC_STRIDE, a.f.nsplit, 0, a.f.epoch);
         }
-        // o_proj operand: the attention output, once every kv head's merged slices are in memory (E3)
+    }
+    O3V_LSTAMP(3);
+    if (!attn_wg) {
+        // The stream starts, PACED: a row is requested when the one before it has landed, so a wave has 7 KiB in flight, not 21 --
+        // the CU's memory pipeline is a queue, and everything the attention chain does on this CU (K/V tiles, q, partials, tickets,
+        // polls) waits behind whatever bulk is queued there.  Three rows per wave still land long before the chain ends.
+        if (n_o >= 1) {
+            res0 = asm_load_bf16(a.f.x + Go);  // requested ahead of its row: loads return in order, it is there when the row is
+            lb_load<NS>(b2, a.f.o_w, Go);
+        } else {
+            lb_load<NS>(b2, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(1)));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lb_load<NS>(b1, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(0)));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n_o == 2) {
+            res1 = asm_load_bf16(a.f.x + Go + NWo);
+            lb_load<NS>(b0, a.f.o_w, Go + NWo);
+        } else {
+            lb_load<NS>(b0, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(2)));
+        }
+        // ---- o_proj: its operand is the attention output, once every kv head's merged slices are in memory (E3).  The rows in the
+        // buffers were requested 10+ us ago: vmcnt(0) costs nothing here.
         if (wave == 0) spin_until<8>(box, Hkv, a.f.epoch, a.f.sync + SYNC_TMO, 0x200u);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __syncthreads();
+        lds_barrier();
         {
             const int nch = (Hq * D) >> 3;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.f.att, 0, Hq * D * 2, 0x00020000);
             for (int c = threadIdx.x; c < nch; c += 256) *reinterpret_cast<u32x4*>(smem + (size_t)c * 16) = load16_sc1(rs, (uint32_t)c * 16);
         }
-        __syncthreads();
-        lb_stream<NS>(P, a, E, true, box, smem);
+        lds_barrier();
+        O3V_LSTAMP(4);
+        lb_wait<NS>(b2, 0);
+        lb_wait<NS>(b0, 0);
+        asm_tie(res0);
+        asm_tie(res1);
+        if (n_o >= 1) {
+            const float acc = lb_dot<NS>(b2, smem);
+            if (lane == 0) {
+                float v = acc + 0.f;  // no bias (TF:620)
+                v = rbf(v) + bf2f((bf16_t)res0);
+                gemv_store_bf16<true>(a.f.xout + Go, f2bf(v));
+            }
+        }
+        if (n_o == 2) {
+            const float acc = lb_dot<NS>(b0, smem);
+            if (lane == 0) {
+                float v = acc + 0.f;
+                v = rbf(v) + bf2f((bf16_t)res1);
+                gemv_store_bf16<true>(a.f.xout + Go + NWo, f2bf(v));
+            }
+        }
+        lb_ticket<false>(a);  // E4: this workgroup's rows of the residual stream are in memory (every wave arrives, also one without rows)
+        // one freed buffer takes its gate/up row BEFORE the wait for x' (it travels during the hand-off), the other after it (the
+        // x' chunks must not queue behind two rows per wave)
+        if (n_o >= 1) lb_load<NS>(b2, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(1)));
+        O3V_LSTAMP(5);
+        lb_enter_gu(a, box, smem);
+        if (n_o == 2) lb_load<NS>(b0, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(2)));
+        O3V_LSTAMP(6);
+        // rows requested after row 0 (buffer 1): row 2 or its refill, and row 1's refill; after row 1 (buffer 2): see the order above
+        lb_gu_loop<NS>(b0, b1, b2, a, R, n_rows, n_o >= 1 ? 2 : 1, n_o == 1 ? 1 : 2, smem);
+        O3V_LSTAMP(7);
         return;
     }
-    // ---- attention workgroup: one (kv head, context split) item -- nothing of the row pipeline is live across it -- then its
-    // share of the gate/up rows
+    // ---- attention workgroup: one (kv head, context split) item -- no weight row is live across it -- then its gate/up rows
     {
         const int t = bid, split = t % a.f.nsplit, hk = t / a.f.nsplit;
         AttnHandoff ho{box,
@@ -592,14 +667,16 @@ __global__ __launch_bounds__(256, 3) void decode_layer_block_kernel(LayerArgs a)
                                     a.f.nsplit, hk, 0, smem, ho);
     }
     __syncthreads();  // the attention scratch is dead: the operand vector of gate/up goes there
-    RowPipe<NS> P2;
-    lb_issue<2, NS>(P2, a, E.next());
-    lb_issue<0, NS>(P2, a, E.next());
-    lb_issue<1, NS>(P2, a, E.next());
+    O3V_LSTAMP(4);
+    u32x4 c0[NS], c1[NS], c2[NS];
+    lb_load<NS>(c1, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(0)));
     lb_enter_gu(a, box, smem);
-    lb_stream<NS>(P2, a, E, false, box, smem);
+    lb_load<NS>(c2, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(1)));
+    lb_load<NS>(c0, a.gu_w, __builtin_amdgcn_readfirstlane(R.row(2)));
+    O3V_LSTAMP(6);
+    lb_gu_loop<NS>(c0, c1, c2, a, R, n_rows, 2, 2, smem);
+    O3V_LSTAMP(7);
 }
-
 
 // o_proj row lengths built (steps of 64 chunks): bf16 rows of 1792 (fixtures) / 2048 (3B) / 3584 (7B) / 4096 (8B class) take
 // 4 / 4 / 7 / 8 steps, their fp8 forms 2 / 2 / 4 / 4
@@ -768,7 +845,7 @@ extern "C" int o3v_decode_layer_block(void* x, const void* ln1, float eps, const
     const int nb_attn = nsplit * Hkv;
     if (n_wg <= 0 || nb_attn > 512 || nb_attn >= n_wg) return O3V_ERR_SHAPE;
     const int n_o_wg = n_wg - nb_attn;
-    if (n_o_wg > 1024 || NQKV / 2 > n_wg * 4 || H > 2 * n_o_wg * 4) return O3V_ERR_SHAPE;  // one rotary pair, two o_proj rows per wave
+    if (n_o_wg > 1024 || NQKV / 2 > n_wg * 4 || ((NQKV / 2) & 3) || H > 2 * n_o_wg * 4 || I < 2 * n_wg * 4) return O3V_ERR_SHAPE;  // one rotary pair, two o_proj rows per wave; the waves of a workgroup all own a pair or none
     LayerArgs a;
     a.f.qkv_s = nullptr;
     a.f.o_s = nullptr;
@@ -797,7 +874,7 @@ extern "C" int o3v_decode_layer_block(void* x, const void* ln1, float eps, const
     a.f.nb_attn = nb_attn;
     a.f.nb_o = 0;
 #ifdef O3V_STAMPS
-    a.f.stamps = nullptr;
+    a.f.stamps = g_stamps;
     a.f.knob = 0;
 #endif
     a.ln2 = (const bf16_t*)ln2;

@@ -70,7 +70,10 @@ class O3VEngine:
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
         self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
-        self.layer_block = os.environ.get("O3V_LAYER_BLOCK", "1") != "0"           # A/B switch for the persistent layer block
+        # the persistent layer block (o3v_decode_layer_block: attention half + gate/up as one launch of resident, row-pipelined
+        # workgroups) is bit-identical but measured SLOWER than the role block + gate/up launch (95.3 vs 90.3 us per layer at 7B,
+        # profiles/r03_layer_block_timeline_v2.txt): off unless O3V_LAYER_BLOCK=1
+        self.layer_block = os.environ.get("O3V_LAYER_BLOCK", "0") == "1"
         # video rope arithmetic (indexing.rope_index): "tf5" = transformers 5.15 (goldens G5b / G14 / G15), "pinned" = the
         # libraries the reference installs (transformers @336dc69d, vllm 0.7.2).  The facades choose; images do not depend on it.
         self.position_mode = "tf5"

@@ -1292,7 +1292,7 @@ def test_decode_attn_block_fp8_equals_three_launches(dev, Hq, Hkv, H, ctx, Tmax,
     (28, 4, 3584, 18944, 4491, 5002, 37, 0),     # 7B, first decode step of the bench prompt
     (28, 4, 3584, 18944, 5002, 5002, 40, 37),    # last slot of the cache, left-padded prompt
     (16, 2, 2048, 11008, 1500, 1732, 14, 0),     # 3B dims (n_rep 8)
-    (16, 2, 2048, 2752, 40, 64, 1, 0),           # fixture dims (tests/fixture_models.py tied3b), one split
+    (16, 2, 2048, 11008, 40, 64, 1, 0),          # 3B dims, one split
     (28, 4, 3584, 18944, 97, 20480, 64, 3),      # few keys against 64 splits: most attention items hold no key at all
     (28, 4, 3584, 18944, 1, 64, 1, 0),           # one key (the token itself)
 ])
