@@ -19,6 +19,7 @@
 // number of workgroups the chip holds at once (occupancy query x CUs), so waiting workgroups can never fill every slot
 // and the q/k/v workgroups always find room.  Spins are bounded and the give-up is sticky.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "o3v_attn_decode_body.h"
 #include "o3v_common.h"
@@ -204,12 +205,17 @@ __global__ __launch_bounds__(256, 3) void decode_attn_block_kernel(FusedArgs a) 
     O3V_STAMP(O3V_STAMP_PTR(a), 3);
 }
 
+// The in-launch hand-offs rest on gfx950 behaviour that was measured, not on a portable memory-model guarantee (o3v_handoff.h): refuse
+// the one-launch forms on anything else (the callers then take the stand-alone kernels)
+static bool device_is_gfx950(const hipDeviceProp_t& prop) { return strncmp(prop.gcnArchName, "gfx950", 6) == 0; }
+
 // workgroups of this kernel the chip holds at once (0: query failed)
 template <int NSTEP, int WB, bool QKN = false>
 int fused_capacity(size_t shmem) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (!device_is_gfx950(prop)) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_block_kernel<NSTEP, WB, QKN>, 256, shmem) != hipSuccess) return 0;
     // the query can over-report for SGPR-heavy kernels, never below 6 workgroups per CU (MI355X_MICROARCH.md, Residency)
     if (per_cu > 6) per_cu = 6;
@@ -815,6 +821,7 @@ static int layer_block_capacity() {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (!device_is_gfx950(prop)) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_layer_block_kernel<NS>, 256, ATTN_LDS) != hipSuccess) return 0;
     if (per_cu < 3) return 0;
     return 3 * prop.multiProcessorCount;  // the grid: three workgroups per CU, all resident

@@ -15,6 +15,14 @@ namespace {
 //               line's memory channel and stretched the q/k/v role's tail from 10 to 16 us), the workgroup meets at a
 //               barrier, and EVERY load of the payload is an sc1 load (L1 bypassed: no stale line of this CU can be read;
 //               the per-XCD L2s are kept coherent for local HBM by the memory probes).
+// What this relies on (gfx950, measured on MI355X in SPX mode; NOT the HSA memory model's release / acquire): (a) an sc1 store is
+// written through this XCD's L2 to memory, and the storing wave's `s_waitcnt vmcnt(0)` returns only when that write has been
+// acknowledged; (b) an sc1 load bypasses the CU's L1 and is served by the L2 / memory side that holds the written-through line; (c)
+// the ticket is a returning agent-scope atomic executed at the L2 / memory side, issued by program order after (a).  Every atomic
+// is relaxed: an agent-scope RELEASE would add `buffer_wbl2` (a write-back of the whole L2) per hand-off, an ACQUIRE a `buffer_inv`.
+// Because this is behaviour of one part in one partition mode, the launchers refuse the one-launch forms unless the device
+// reports gfx950 (o3v_fused.hip: device_is_gfx950), every wait is bounded, and the engine re-runs a call on the stand-alone kernels
+// when a wait gives up (engine.generate).
 // Nothing is zeroed between launches: the buffer is zeroed once per generate call, the epoch e = 1, 2, ... is the launch's
 // index in that call, the tickets count on (the last ticket of episode e is e * want - 1) and a mailbox holds the last
 // epoch it was told.  Every spin is bounded and the give-up is sticky (one time-out makes every later wait return at once).

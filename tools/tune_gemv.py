@@ -36,6 +36,10 @@ def main():
         "gate_up": (2 * I, H, 3, True), "down": (H, I, 1, False), "o_proj": (H, H, 1, False), "qkv": (4608, H, 0, True),
         "lm_head": (152064, H, 0, True),
     }
+    if "--3b" in sys.argv:        # BASELINE config #1: Qwen2.5-VL-3B dims (36 layers of 2048 / 11008, GQA 16:2, vocabulary 151936)
+        H, I = 2048, 11008
+        shapes = {"gate_up": (2 * I, H, 3, True), "down": (H, I, 1, False), "o_proj": (H, H, 1, False), "qkv": (2560, H, 0, True),
+                  "lm_head": (151936, H, 0, True)}
     if "--balance" in sys.argv:   # does a grid that divides evenly over the 256 CUs stream faster?  (gate/up: 2368 blocks = 9.25 per CU)
         shapes = {"gate_up": (2 * I, H, 3, True), "gu_2048blk": (2 * 16384, H, 3, True), "gu_2560blk": (2 * 20480, H, 3, True),
                   "gu_4096blk": (2 * 32768, H, 3, True), "down": (H, I, 1, False), "down_4096": (4096, I, 1, False)}
