@@ -93,9 +93,9 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 // hipGetLastError() reports the last error of ANY earlier runtime call of this host thread (torch's own included),
 // so clear it right before our launch and read it right after.
-// o3v_tl_launches: kernel launches enqueued by this host thread (defined in o3v_engine.hip); o3v_llm_decode reports the
+// o3v_tl_launches: kernel launches enqueued by this host thread; o3v_llm_decode reports the
 // launches per decode layer from it (o3v_decode_state.host_stats)
-extern thread_local long long o3v_tl_launches;
+inline thread_local long long o3v_tl_launches = 0;  // (C++17 inline variable: one instance per thread for the whole library)
 #define O3V_KLAUNCH(...)               \
     do {                               \
         (void)hipGetLastError();       \

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "../../include/o3v.h"
+#include "o3v_common.h"
 
 #define TRY(expr)                 \
     do {                          \
@@ -51,7 +52,6 @@ int linear(const void* A, const void* W, const void* bias, const void* res, void
 
 }  // namespace
 
-thread_local long long o3v_tl_launches = 0;
 extern "C" int o3v_abi_version(void) { return 6; }
 
 // ------------------------------------------------------------------------------------------------ context handle

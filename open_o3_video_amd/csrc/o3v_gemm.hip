@@ -708,7 +708,7 @@ int launch_gemv(const GemvArgs& a) {
     const int outs = (a.epi == EPI_SWIGLU || a.epi == EPI_QKVROPE) ? a.N / 2 : a.N;
     const int per_block = per_wave * (NW / KS);
     dim3 grid((outs + per_block - 1) / per_block), block(NW * 64);
-    const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)NW * R * M * 4 + (NORM ? NW * M * 4 : 0);
+    const size_t shmem = (NORM ? (size_t)M * a.K * 2 : 0) + (size_t)NW * R * M * 4 + (NORM ? 4 * M * 4 : 0);  // x, split-K partials, 4 virtual-wave sums
     if (shmem > 160 * 1024) return O3V_ERR_SHAPE;
 #define O3V_GV(E)                                                                                                             \
     O3V_KLAUNCH((gemv_bf16_kernel<M, R, KS, E, NORM, NW, WB, UU>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, \
@@ -949,21 +949,24 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     const size_t shmem = (NORM ? (size_t)M * (a.K * 2 + 16) : 0) + (KS > 1 ? (size_t)4 * RB * 64 * 16 : 0) + (NORM ? 16 * 4 * 4 : 0);
     const size_t shmem2 = KS > 1 ? (size_t)4 * RB * 2 * 64 * 16 : 0;  // two column blocks of split-K partials
 #ifdef O3V_TUNE
-    if (g_mt_ut == 16) {
-        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 16>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
-                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
-        return O3V_OK;
+#define O3V_TUNE_UT(U)                                                                                                         \
+    if (g_mt_ut == U) {                                                                                                        \
+        if (M > 16) {                                                                                                          \
+            if constexpr (!NORM) {                                                                                             \
+                O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, U, 2>), grid, block, shmem2, a.s, a.X, a.W, a.bias,      \
+                            a.res, a.out, a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);                     \
+                return O3V_OK;                                                                                                 \
+            }                                                                                                                  \
+            return O3V_ERR_SHAPE;                                                                                              \
+        }                                                                                                                      \
+        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, U>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out,     \
+                    a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);                                           \
+        return O3V_OK;                                                                                                         \
     }
-    if (g_mt_ut == 4) {
-        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 4>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
-                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
-        return O3V_OK;
-    }
-    if (g_mt_ut == 8) {
-        O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, 8>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w,
-                    a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
-        return O3V_OK;
-    }
+    O3V_TUNE_UT(16)
+    O3V_TUNE_UT(4)
+    O3V_TUNE_UT(8)
+#undef O3V_TUNE_UT
 #endif
     // 16 KiB of weight loads in flight per wave for the single-block epilogues, 8 KiB for the paired (gate/up, q/k/v) ones:
     // A/B on the 7B shapes in profiles/r01_m8_linear.txt

@@ -194,51 +194,73 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         // ---- block-wide RMSNorm of x into LDS: xs[m][k] = bf16(w[k] * bf16(x[m][k] * rstd[m])).
         // x (a few KiB, L2-resident) is requested first, then the first trip of weight loads, so that the
         // HBM latency of the weights runs under the norm instead of after it.
-        constexpr int XC = (512 + NT - 1) / NT;      // x chunks per thread kept in registers (K <= 4096)
-        const bool small = (nxc <= XC * NT) && (M <= 4);
-        u32x4 xr[XC][M <= 4 ? M : 1], wnr[XC];  // x chunks and the norm-weight chunks that go with them: one latency, not two
-        float ss[M];
+        // The sum of squares is added in ONE order whatever the workgroup size: 256 virtual threads t (chunks t, t + 256, ...
+        // ascending, one fmaf chain each), 4 virtual waves of 64 (the wave_sum butterfly), their sums added 0..3.  Real wave w
+        // plays the virtual waves w, w + NW, ... -- with 4 waves exactly its own, with fewer several, waves past the fourth
+        // none.  So rstd, and with it every normalised element, does not depend on the decomposition the launcher picked
+        // (or on which kernel -- stand-alone, one-launch block, norm_finish of the layer block -- computes it).
+        constexpr int VW = (4 + NW - 1) / NW;        // virtual waves per real wave (at most)
+        constexpr int XC = 2;                        // chunks per virtual thread kept in registers (K <= 4096)
+        const bool small = (nxc <= XC * 256) && (M <= 4);
+        u32x4 xr[VW][XC][M <= 4 ? M : 1], wnr[VW][XC];  // x chunks and the norm-weight chunks that go with them: one latency, not two
+        float ss[VW][M];
 #pragma unroll
-        for (int m = 0; m < M; ++m) ss[m] = 0.f;
+        for (int v = 0; v < VW; ++v)
+#pragma unroll
+            for (int m = 0; m < M; ++m) ss[v][m] = 0.f;
         if (small) {
 #pragma unroll
-            for (int i = 0; i < XC; ++i) {
-                const int c = threadIdx.x + i * NT;
+            for (int v = 0; v < VW; ++v)
 #pragma unroll
-                for (int m = 0; m < (M <= 4 ? M : 1); ++m)
-                    xr[i][m] = c < nxc ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
-                wnr[i] = c < nxc ? *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
-            }
+                for (int i = 0; i < XC; ++i) {
+                    const int vw = wave + v * NW;
+                    const int c = vw * 64 + lane + i * 256;
+                    const bool in = vw < 4 && c < nxc;
+#pragma unroll
+                    for (int m = 0; m < (M <= 4 ? M : 1); ++m)
+                        xr[v][i][m] = in ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+                    wnr[v][i] = in ? *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
+                }
         }
         if (c_begin < c_end) load_w(c_begin);
         if (small) {
 #pragma unroll
-            for (int i = 0; i < XC; ++i)
+            for (int v = 0; v < VW; ++v)
 #pragma unroll
-                for (int m = 0; m < (M <= 4 ? M : 1); ++m)
+                for (int i = 0; i < XC; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ss[m] = fmaf(bf_lo(xr[i][m][j]), bf_lo(xr[i][m][j]), ss[m]);
-                        ss[m] = fmaf(bf_hi(xr[i][m][j]), bf_hi(xr[i][m][j]), ss[m]);
-                    }
+                    for (int m = 0; m < (M <= 4 ? M : 1); ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ss[v][m] = fmaf(bf_lo(xr[v][i][m][j]), bf_lo(xr[v][i][m][j]), ss[v][m]);
+                            ss[v][m] = fmaf(bf_hi(xr[v][i][m][j]), bf_hi(xr[v][i][m][j]), ss[v][m]);
+                        }
         } else {
-            for (int c = threadIdx.x; c < nxc; c += NT) {
 #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+            for (int v = 0; v < VW; ++v) {
+                const int vw = wave + v * NW;
+                for (int c = vw * 64 + lane; vw < 4 && c < nxc; c += 256) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ss[m] = fmaf(bf_lo(v[j]), bf_lo(v[j]), ss[m]);
-                        ss[m] = fmaf(bf_hi(v[j]), bf_hi(v[j]), ss[m]);
+                    for (int m = 0; m < M; ++m) {
+                        const u32x4 xv4 = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ss[v][m] = fmaf(bf_lo(xv4[j]), bf_lo(xv4[j]), ss[v][m]);
+                            ss[v][m] = fmaf(bf_hi(xv4[j]), bf_hi(xv4[j]), ss[v][m]);
+                        }
                     }
                 }
             }
         }
-        float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + NW * R * M * 4);
+        float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + NW * R * M * 4);  // [4 virtual waves][M]
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            ss[m] = wave_sum(ss[m]);
-            if (lane == 0) red[wave * M + m] = ss[m];
+        for (int v = 0; v < VW; ++v) {
+            const int vw = wave + v * NW;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                ss[v][m] = wave_sum(ss[v][m]);
+                if (lane == 0 && vw < 4) red[vw * M + m] = ss[v][m];
+            }
         }
         __syncthreads();
         float rstd[M];
@@ -247,7 +269,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         {
             float t = red[m];
 #pragma unroll
-            for (int w2 = 1; w2 < NW; ++w2) t += red[w2 * M + m];
+            for (int w2 = 1; w2 < 4; ++w2) t += red[w2 * M + m];
             rstd[m] = 1.0f / sqrtf(t / (float)K + eps);
         }
         auto norm_store = [&](int c, int m, const u32x4& v, const u32x4& wn) {
@@ -259,15 +281,18 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         };
         if (small) {
 #pragma unroll
-            for (int i = 0; i < XC; ++i) {
-                const int c = threadIdx.x + i * NT;
-                if (c < nxc) {
+            for (int v = 0; v < VW; ++v)
 #pragma unroll
-                    for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[i][m], wnr[i]);
+                for (int i = 0; i < XC; ++i) {
+                    const int vw = wave + v * NW;
+                    const int c = vw * 64 + lane + i * 256;
+                    if (vw < 4 && c < nxc) {
+#pragma unroll
+                        for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[v][i][m], wnr[v][i]);
+                    }
                 }
-            }
         } else {
-            for (int c = threadIdx.x; c < nxc; c += NT) {
+            for (int c = threadIdx.x; c < nxc; c += NT) {   // element-wise: any assignment
                 const u32x4 wn = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * 8);
 #pragma unroll
                 for (int m = 0; m < M; ++m)

@@ -531,7 +531,7 @@ class O3VEngine:
 
         while done < T:
             # the first chunk is short whenever the one-launch block is in use: its time-out word is read right after it
-            n = min(chunk if (done or sync is None) else min(chunk, 16), T - done)
+            n = min(chunk if (done or sync is None) else min(chunk, getattr(self, "_first_chunk", 16)), T - done)
             _lib.call("o3v_llm_decode", C.byref(self.w.llm), C.byref(st), done, n, int(done + n == T), _stream())
             first = done == 0
             done += n
@@ -545,6 +545,9 @@ class O3VEngine:
         tm["launches_per_layer"] = (stats[1] / layers_run) if layers_run else None
         tm["fused_attention_layers"], tm["standalone_attention_layers"] = int(stats[2]), int(stats[3])
         check_waits()
+        if getattr(self, "_debug_keep", False):     # probe hook: the decode's state after the last step
+            self._debug_last = {"kc": kc, "vc": vc, "logits": logits, "x": xdec, "S": S, "cos": cosd, "sin": sind, "k_lo": k_lo,
+                                "nsplit": nsplit, "Tmax": Tmax, "out_ids": out_ids}
         gen = out_ids[:, :done].to(torch.int64)
         if use_eos and done > 0:
             # HF stops at the step where every row has finished: trim trailing all-pad columns generated past it

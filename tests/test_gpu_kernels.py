@@ -1362,3 +1362,26 @@ def test_decode_layer_block_equals_stand_alone_launches(dev, Hq, Hkv, H, I, ctx,
         assert torch.equal(att2.view(torch.int16), att1.view(torch.int16))
         assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
         assert torch.equal(act2.view(torch.int16), act1.view(torch.int16))
+
+
+def test_fused_rmsnorm_does_not_depend_on_the_decomposition(dev):
+    """The RMSNorm prologue of the weight-streaming GEMV adds the squares in one order whatever workgroup size the launcher picks
+    (o3v_gemv_body.h: 256 virtual threads, 4 virtual waves): the same weight rows give the same bits through a 6144-row call (3 waves
+    per workgroup at K = 4096), a 2048-row call (4 waves) and the gate/up form of a 2-wave workgroup is covered by the layer-block
+    test.  x has a wide dynamic range so that the order of the additions matters; before the order was fixed the one-launch attention
+    block (4 waves) and the stand-alone q/k/v launch (3 waves) differed about once in 500 layer evaluations."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    K, N1, N2 = 4096, 6144, 2048
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(N1, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for trial in range(96):
+        x = (torch.randn(1, K, generator=g) * torch.exp(1.5 * torch.randn(1, K, generator=g))).to(BF).to(dev)
+        o1 = torch.zeros(1, N1, dtype=BF, device=dev)
+        o2 = torch.zeros(1, N2, dtype=BF, device=dev)
+        _lib.call("o3v_linear_decode", P(x), P(nw), 1e-6, P(w), None, None, None, P(o1), 1, N1, K, K, N1, 0, _lib.EPI_NONE, st)
+        _lib.call("o3v_linear_decode", P(x), P(nw), 1e-6, P(w), None, None, None, P(o2), 1, N2, K, K, N2, 0, _lib.EPI_NONE, st)
+        assert torch.equal(o1[:, :N2].view(torch.int16), o2.view(torch.int16)), trial

@@ -43,11 +43,14 @@ for name, (N, K, epi, norm) in shapes.items():
         lib.o3v_gemv_mfma_tune(*v)
         for w, wp in zip(ws, wps):
             rc = lib.o3v_linear_decode(P(x), P(nw) if norm else None, 1e-6, P(w), P(wp), None, P(res), P(out), M, N, K, K, No, N, epi, st)
-            assert rc == 0, rc
-    variants = [(ks, ut) for ks in (1, 2, 4) for ut in (4, 8, 16)]
+            if rc:
+                return rc
+        return 0
+    if norm and M > 16:
+        continue                      # above 16 rows the linears take no fused norm
+    variants = [(0, 0)] + [(ks, ut) for ks in (1, 2, 4) for ut in (4, 8, 16)]   # (0, 0): the library's own choice
+    variants = [v for v in variants if run(v) == 0]
     res_t = {v: [] for v in variants}
-    for v in variants:
-        run(v)
     torch.cuda.synchronize()
     for rnd in range(3):
         for v in variants:
