@@ -138,6 +138,16 @@ int o3v_gemv_norm_qkv_rope(const void* X, const void* norm_w, float eps, const v
 int o3v_linear_decode(const void* X, const void* norm_w, float eps, const void* W, const void* Wp, const void* bias,
                       const void* res, void* out, int M, int N, int K, int ldx, int ldo, int ldr, int epilogue,
                       o3v_stream_t stream);
+/* The residual linears of a batched decode layer (o_proj, down_proj; TF:692-757 `hidden = residual + ...` followed by the next
+ * RMSNorm, TF:65-79) with the NEXT norm folded in: out = X . W^T + res and h = RMSNorm(out; next_norm_w) in ONE launch, 8 <= M <= 32
+ * rows of already normalised X, Wp the fragment-major image, N <= 4096.  The waves that draw the last M tickets of the launch
+ * normalise one row each once every part of `out` is in memory; h is bit-identical to o3v_rmsnorm(out, next_norm_w).  sync: the
+ * zeroed buffer of o3v_decode_sync_bytes() (lines of its own; the sticky time-out word at O3V_SYNC_TMO_BYTE is shared), epoch = 1,
+ * 2, ... counts the calls made on it.  O3V_ERR_SHAPE when the form does not apply (not gfx950, shapes): issue o3v_linear_decode +
+ * o3v_rmsnorm instead. */
+int o3v_linear_decode_norm_next(const void* X, const void* Wp, const void* res, void* out, int M, int N, int K, int ldx, int ldo,
+                                int ldr, const void* next_norm_w, float eps, void* h, int ldh, uint32_t* sync, uint32_t epoch,
+                                o3v_stream_t stream);
 
 /* Decode linears on fp8 (OCP e4m3fn) weights, M <= 3 rows: W8 uint8 [N, K] (K % 16 == 0) with one fp32 scale per output
  * row; out = epi(scale[n] * (rmsnorm(X; norm_w) . fp8(W8[n])) + bias), x and the accumulation as in the bf16 path (the fp8

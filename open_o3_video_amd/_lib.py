@@ -124,6 +124,7 @@ SIGNATURES = {
     "o3v_linear_decode_fp8": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemv_norm_qkv_rope_fp8": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_linear_decode": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_linear_decode_norm_next": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, f32, vp, i32, vp, C.c_uint32, vp],
     "o3v_gemv_norm_bf16": [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_sample_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, u64, vp, i32, i32, vp, vp],
     "o3v_sample_top_k_top_p": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, i32, f32, u64, vp, i32, i32, vp, vp],

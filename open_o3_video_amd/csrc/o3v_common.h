@@ -41,6 +41,58 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- RMSNorm of ONE row by ONE wave (TF:65-79): out = w * bf16(x * rsqrt(mean(x^2) + eps)); the row is held in VGPRs.  Shared by
+// rmsnorm_kernel (o3v_elem.hip) and by the finishing waves of the residual linears that normalise for the next linear
+// (o3v_gemm.hip, TailNorm), so both round identically: chunks lane + 64 i ascending in one fmaf chain, then the wave butterfly.
+// ld_chunk(c) returns the c-th 16-byte chunk of the row (a plain or an L1-bypassing load).
+template <int MAXCH, class LoadChunk>
+__device__ __forceinline__ void rmsnorm_row_wave(LoadChunk ld_chunk, const bf16_t* __restrict__ w, bf16_t* __restrict__ orow_, int cols,
+                                                 float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nch = cols >> 3;  // 16-byte chunks per row
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    uint4 v[MAXCH], wv[MAXCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {  // the weight chunks ride along with the row: one memory latency instead of two
+        int c = lane + i * 64;
+        if (c < nch) wv[i] = wr[c];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = ld_chunk(c);
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = bf_lo(p[j]), b = bf_hi(p[j]);
+                ss = fmaf(a, a, ss);
+                ss = fmaf(b, b, ss);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)cols + eps);
+    uint4* orow = reinterpret_cast<uint4*>(orow_);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + i * 64;
+        if (c < nch) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv[i]);
+            uint4 o;
+            uint32_t* po = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = rbf(bf_lo(p[j]) * rstd), b = rbf(bf_hi(p[j]) * rstd);
+                po[j] = pack_bf2(bf_lo(q[j]) * a, bf_hi(q[j]) * b);
+            }
+            orow[c] = o;
+        }
+    }
+}
+
 // ---- per-head q/k RMSNorm + rotation (Qwen3-VL, TF3:480-484), shared by o3v_qkv_norm_rope_cache and the one-launch decode block
 // so that both round identically.  A "lane share" of a head is an 8-wide chunk of each rotary half (lo: dims 8c.., hi: D/2 + 8c..).
 __device__ __forceinline__ float qkn_chain(const u32x4& lo, const u32x4& hi) {  // sum of squares of a lane share, fixed order

@@ -15,49 +15,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int nch = cols >> 3;  // 16-byte chunks per row
     const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * ld_in);
-    const uint4* wr = reinterpret_cast<const uint4*>(w);
-    uint4 v[MAXCH], wv[MAXCH];
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {  // the weight chunks ride along with the row: one memory latency instead of two
-        int c = lane + i * 64;
-        if (c < nch) wv[i] = wr[c];
-    }
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        int c = lane + i * 64;
-        if (c < nch) {
-            v[i] = xr[c];
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a = bf_lo(p[j]), b = bf_hi(p[j]);
-                ss = fmaf(a, a, ss);
-                ss = fmaf(b, b, ss);
-            }
-        }
-    }
-    ss = wave_sum(ss);
-    const float rstd = 1.0f / sqrtf(ss / (float)cols + eps);
-    uint4* orow = reinterpret_cast<uint4*>(out + (size_t)row * ld_out);
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        int c = lane + i * 64;
-        if (c < nch) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(&v[i]);
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(&wv[i]);
-            uint4 o;
-            uint32_t* po = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a = rbf(bf_lo(p[j]) * rstd), b = rbf(bf_hi(p[j]) * rstd);
-                po[j] = pack_bf2(bf_lo(q[j]) * a, bf_hi(q[j]) * b);
-            }
-            orow[c] = o;
-        }
-    }
+    rmsnorm_row_wave<MAXCH>([&](int c) { return xr[c]; }, w, out + (size_t)row * ld_out, cols, eps);
 }
 
 extern "C" int o3v_rmsnorm(const void* x, const void* w, void* out, int rows, int cols, int ld_in, int ld_out,

@@ -402,17 +402,20 @@ extern "C" int o3v_llm_prefill_ex(const o3v_llm_desc* d, void* x, const void* co
 }
 
 namespace {
-int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s);
+int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s,
+             bool pre_normed = false);
 }
 // bf16 weights always: the head of the prefill, of forward_logits and of the log-prob pass (R:grpo_trainer.py:371-384) -- the fp8
 // rows are DECODE rows (o3v_llm_decode streams them), a log-prob must not depend on how many rows its chunk happens to hold
 extern "C" int o3v_llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits,
                             o3v_stream_t s) {
-    return llm_head(d, x, ldx, rows, normed, logits, false, s);
+    return llm_head(d, x, ldx, rows, normed, logits, false, s, false);
 }
 
 namespace {
-int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s) {
+// pre_normed: `normed` already holds RMSNorm(x; final_norm) (the last down_proj of a batched decode step normalised it, TailNorm)
+int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* normed, void* logits, bool fp8_rows, o3v_stream_t s,
+             bool pre_normed) {
     if (!d || !x || !normed || !logits || rows <= 0) return O3V_ERR_ARG;
     const int H = d->hidden;
     if (fp8_rows && rows >= 4 && rows <= 32 && d->lm_head8p) {  // batched decode on fp8 rows: norm apart, fp8 fragments widened in registers
@@ -421,7 +424,7 @@ int llm_head(const o3v_llm_desc* d, const void* x, int ldx, int rows, void* norm
                                           O3V_EPI_NONE, s);
     }
     if (rows >= 8 && rows <= 32 && d->lm_head_p) {  // batched decode: norm apart, LDS-free matrix-core linear
-        TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
+        if (!pre_normed) TRY(o3v_rmsnorm(x, d->final_norm, normed, rows, H, ldx, H, d->rms_eps, s));
         return o3v_linear_decode(normed, nullptr, 0.f, d->lm_head, d->lm_head_p, nullptr, nullptr, logits, rows, d->vocab, H, H,
                                  d->vocab, 0, O3V_EPI_NONE, s);
     }
@@ -482,6 +485,12 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // the persistent layer block (attention half + gate/up in one launch): bf16 rows, no q/k norm
     bool layer_block = fused && (st->flags & 1) && !fp8 && !qk_norm;
     int step = step0;
+    // 8..32 bf16 rows: the residual linears normalise for the linear that follows (o3v_linear_decode_norm_next), so only layer 0's
+    // first norm of a step is a launch of its own.  st->flags & 2 switches it off (A/B, tests).
+    bool tail = norm_apart && !fp8b && st->sync && !(st->flags & 2) && d->lm_head_p && d->layer[0].o_wp && d->layer[0].down_wp;
+    bool h_ready = false;       // w.h holds RMSNorm(x; ln1 of the layer about to run)
+    bool h2_ready = false;      // w.h holds RMSNorm(x; ln2 of the running layer)
+    bool normed_ready = false;  // w.normed holds RMSNorm(x; final_norm)
     // host_stats (optional, host memory): [0] += decode forwards, [1] += kernel launches inside their layer loops, [2] += layers whose
     // attention half ran as the one-launch block, [3] += layers whose attention half ran on the stand-alone kernels
     long long* hs = (long long*)st->host_stats;
@@ -498,7 +507,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                 TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode_fp8_rows(w.h, lw.qkv_w8p, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
             } else if (norm_apart) {  // (above 16 rows the linears take no fused norm at all)
-                TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+                if (!h_ready) TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
             } else
                 TRY(o3v_linear_decode(st->x, lw.ln1, d->rms_eps, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0,
@@ -513,7 +522,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
                                            kc, vc, slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         } else if (norm_apart) {
-            TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
+            if (!h_ready) TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
             TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
                                        slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
         } else {
@@ -532,8 +541,21 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             TRY(o3v_linear_decode_fp8(w.att, nullptr, 0.f, lw.o_w8, lw.o_s, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
         else if (fp8b)
             TRY(o3v_linear_decode_fp8_rows(w.att, lw.o_w8p, lw.o_s, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
-        else
+        else {
+            h_ready = h2_ready = false;
+            if (tail) {
+                const uint32_t epoch = (uint32_t)(step * d->layers + l) * 2u + 1u;
+                const int rc = o3v_linear_decode_norm_next(w.att, lw.o_wp, st->x, st->x, B, H, QD, QD, H, H, lw.ln2, d->rms_eps, w.h, H,
+                                                           st->sync, epoch, s);
+                if (rc == O3V_OK) {
+                    h2_ready = true;
+                    return O3V_OK;
+                }
+                if (rc != O3V_ERR_SHAPE || l != 0 || step != step0) return rc;
+                tail = false;  // not this device / these shapes: two launches, for the whole call
+            }
             TRY(o3v_linear_decode(w.att, nullptr, 0.f, lw.o_w, lw.o_wp, nullptr, st->x, st->x, B, H, QD, QD, H, H, O3V_EPI_RESIDUAL, s));
+        }
         return O3V_OK;
     };
     for (int i = 0; i < n_steps; ++i) {
@@ -550,6 +572,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         if (slot0 + step >= st->Tmax) return O3V_ERR_ARG;
         // one decode forward: token `step` sits in cache slot S+step, context = S+step+1 keys
         if (st->do_sample) TRY(o3v_embed_tokens(d->embed, st->cur_tok, st->x, B, H, s));
+        h_ready = h2_ready = normed_ready = false;  // x is the sampler's embedding row
         const long long launches0 = o3v_tl_launches;
         for (int l = 0; l < d->layers; ++l) {
             const o3v_llm_layer_w& lw = d->layer[l];
@@ -606,9 +629,18 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
                 continue;
             }
             if (norm_apart) {
-                TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
+                if (!h2_ready) TRY(o3v_rmsnorm(st->x, lw.ln2, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
                                       O3V_EPI_SWIGLU, s));
+                h2_ready = false;
+                if (tail) {  // down_proj + the next layer's first norm (the head's norm after the last layer)
+                    const bool last = l + 1 == d->layers;
+                    const uint32_t epoch = (uint32_t)(step * d->layers + l) * 2u + 2u;
+                    TRY(o3v_linear_decode_norm_next(w.mlp, lw.down_wp, st->x, st->x, B, H, I, I, H, H, last ? d->final_norm : d->layer[l + 1].ln1,
+                                                    d->rms_eps, last ? w.normed : w.h, H, st->sync, epoch, s));
+                    (last ? normed_ready : h_ready) = true;
+                    continue;
+                }
             } else {
                 TRY(o3v_linear_decode(st->x, lw.ln2, d->rms_eps, lw.gu_w, lw.gu_wp, nullptr, nullptr, w.mlp, B, 2 * I, H, H, I, 0,
                                       O3V_EPI_SWIGLU, s));
@@ -621,7 +653,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             hs[1] += o3v_tl_launches - launches0;
         }
         // the head follows the layers: fp8 rows only when the layer stack of this call streams fp8 rows
-        TRY(llm_head(d, st->x, H, B, w.normed, st->logits, fp8 || fp8b, s));
+        TRY(llm_head(d, st->x, H, B, w.normed, st->logits, fp8 || fp8b, s, normed_ready));
     }
     return O3V_OK;
 }

@@ -12,6 +12,7 @@
 // the XOR swizzle applied to the per-lane SOURCE address and to the ds_read_b128 (both sides), which
 // makes every ds_read_b128 lane-group conflict-free on the 128-byte tile rows.  Two LDS buffers, one
 // barrier per K-tile (the stage of tile t+1 is issued before the MFMAs of tile t).
+#include <cstring>
 #include "o3v_common.h"
 #include "o3v_gemv_body.h"
 
@@ -228,12 +229,28 @@ __global__ __launch_bounds__(NW * 64) void gemv_bf16_kernel(const bf16_t* __rest
 // NORM: RMSNorm of x fused, normalised rows kept in LDS with a 16-byte row skew (conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------------
 // CB: 16-row column blocks of x (M <= 16 * CB): every weight fragment feeds CB MFMAs, so 17..32 rows still stream the weights once.
+//
+// TailNorm (EPI_RESIDUAL, 8..32 rows): the linear also produces h = RMSNorm(out; w) for the NEXT linear, so the stand-alone norm
+// launch between them (5.9 us at 8 rows x 3584, nearly all of it launch boundary) disappears.  Protocol of o3v_handoff.h: every
+// storing wave writes its part of `out` through (sc1), drains its stores and draws a ticket; the waves that draw the LAST M tickets
+// of the launch each take one row -- they wait until the very last ticket holder has published the epoch, read their row past L1
+// (sc1) and normalise it with rmsnorm_row_wave, i.e. the code and the rounding of rmsnorm_kernel: h is bit-identical to
+// o3v_rmsnorm(out).  The grid (N / 16 row groups, <= 256 workgroups) is resident at once, the waits are bounded and sticky.
+struct TailNorm {
+    uint32_t* sync = nullptr;   // nullptr: off.  Ticket line, "all stored" line and the time-out word (O3V_SYNC_TAIL_*, O3V_SYNC_TMO_WORD)
+    uint32_t epoch = 0, total = 0;  // 1, 2, ...: index of this launch among those sharing the lines; storing waves per launch
+    const bf16_t* w = nullptr;  // the next RMSNorm's weight [N]
+    bf16_t* h = nullptr;        // [M, ldh] normalised rows
+    int ldh = 0;
+    float eps = 0.f;
+};
+
 template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8, int CB = 1>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
                                                         float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
-                                                        RopeArgs ra) {
+                                                        RopeArgs ra, TailNorm tn) {
     constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
     constexpr int RG = 4 / KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M x (K*2+16)] [KS>1: 4 x RB x 64 x 4 f32] [red]
@@ -480,9 +497,29 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
             if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[cb][r];
             if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
             if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
-            out[(size_t)m * ldo + n] = f2bf(v);
+            if (EPI == EPI_RESIDUAL && tn.sync)
+                gemv_store_bf16<true>(out + (size_t)m * ldo + n, f2bf(v));  // written through: another XCD's wave normalises the row
+            else
+                out[(size_t)m * ldo + n] = f2bf(v);
         }
     }
+    }
+    if constexpr (EPI == EPI_RESIDUAL) {
+        if (!tn.sync) return;  // kernel-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of `out` is in memory
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(tn.sync + O3V_SYNC_TAIL_TICKET, 1u, O3V_RLX_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        const uint32_t idx = old - (tn.epoch - 1u) * tn.total;  // 0 .. total-1 within this launch
+        if (idx + (uint32_t)M < tn.total) return;               // not one of the last M storing waves
+        const int row = (int)(idx + (uint32_t)M - tn.total);
+        // the last ticket holder knows every row is complete; the few others poll the ticket line itself (at most 31 pollers, and
+        // only while the last storing waves arrive: one hop less than a separate "done" word)
+        if (idx != tn.total - 1u)
+            spin_until<1>(tn.sync + O3V_SYNC_TAIL_TICKET, 1, tn.epoch * tn.total, tn.sync + O3V_SYNC_TMO_WORD, 0x500u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)row * ldo), 0, N * 2, 0x00020000);
+        rmsnorm_row_wave<8>([&](int c) { return __builtin_bit_cast(uint4, load16_sc1(rs, (uint32_t)c * 16)); }, tn.w,
+                            tn.h + (size_t)row * tn.ldh, N, tn.eps);
     }
 }
 
@@ -700,6 +737,7 @@ struct GemvArgs {
     RopeArgs ra;
     bool packed;  // W points at the MFMA-fragment-major image (M >= 2 path only)
     const float* wscale = nullptr;  // fp8 weights (M <= 3): one dequantisation scale per output row; W then points at bytes
+    TailNorm tn{};                  // matrix-core path, EPI_RESIDUAL: normalise the result for the next linear
 };
 
 template <int M, int R, int KS, bool NORM, int NW = 4, int WB = 2, int UU = 0>
@@ -805,6 +843,9 @@ int launch_gemv_m(const GemvArgs& a) {
     if (M == 1 && WB == 2 && outs >= 32768) return launch_gemv<M, 2, 1, NORM, 3, WB>(a);  // lm_head, one bf16 row: 152.1 us (R = 4: 156)
     if (M == 1 && WB == 1 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 3, WB>(a);  // lm_head, one row of fp8 weights: 80.2 vs 82.0 us
     if (M <= 2 && outs >= 32768) return launch_gemv<M, 4, 1, NORM, 4, WB>(a);     // lm_head
+    // long K, few rows (3B down_proj, 2048 x 11008: 1024 wave groups): four K slices per row pair -> 16 waves per CU; 10.3 vs 11.5 us
+    // (profiles/r03_tune_3b.txt)
+    if (M == 1 && WB == 2 && steps >= 16 && outs <= 2048) return launch_gemv<M, 2, 4, NORM, 4, WB>(a);
     if (steps >= 16) return launch_gemv_balanced<M, 2, NORM, WB>(a);           // long K (down_proj): split K over wave pairs
     return launch_gemv_balanced<M, 1, NORM, WB>(a);                            // o_proj / qkv
 }
@@ -948,19 +989,22 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     dim3 grid((groups + RG - 1) / RG), block(256);
     const size_t shmem = (NORM ? (size_t)M * (a.K * 2 + 16) : 0) + (KS > 1 ? (size_t)4 * RB * 64 * 16 : 0) + (NORM ? 16 * 4 * 4 : 0);
     const size_t shmem2 = KS > 1 ? (size_t)4 * RB * 2 * 64 * 16 : 0;  // two column blocks of split-K partials
+    TailNorm tn = a.tn;
+    tn.total = grid.x * RG;  // storing waves: one per row group (with a K split the slice-0 wave of each workgroup)
+    if (tn.sync && (EPI != EPI_RESIDUAL || tn.total < (uint32_t)M)) return O3V_ERR_SHAPE;
 #ifdef O3V_TUNE
 #define O3V_TUNE_UT(U)                                                                                                         \
     if (g_mt_ut == U) {                                                                                                        \
         if (M > 16) {                                                                                                          \
             if constexpr (!NORM) {                                                                                             \
                 O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, U, 2>), grid, block, shmem2, a.s, a.X, a.W, a.bias,      \
-                            a.res, a.out, a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);                     \
+                            a.res, a.out, a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn);                 \
                 return O3V_OK;                                                                                                 \
             }                                                                                                                  \
             return O3V_ERR_SHAPE;                                                                                              \
         }                                                                                                                      \
         O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, U>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out,     \
-                    a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);                                           \
+                    a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn);                                       \
         return O3V_OK;                                                                                                         \
     }
     O3V_TUNE_UT(16)
@@ -976,13 +1020,13 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
         // per wave so that the doubled x fragments and accumulators fit the register file
         if constexpr (!NORM) {
             O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, 8, 2>), grid, block, shmem2, a.s, a.X, a.W, a.bias, a.res, a.out,
-                        a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+                        a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn);
             return O3V_OK;
         }
         return O3V_ERR_SHAPE;
     }
     O3V_KLAUNCH((gemv_mfma_kernel<EPI, NORM, KS, PACKED, UT>), grid, block, shmem, a.s, a.X, a.W, a.bias, a.res, a.out, a.norm_w, a.eps,
-                M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra);
+                M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn);
     return O3V_OK;
 }
 
@@ -1021,7 +1065,7 @@ static int launch_gemv_mfma(const GemvArgs& a, int M) {
 static int gemv_dispatch(const void* X, const void* W, const void* bias, const void* res, void* out, const void* norm_w,
                          float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, int epilogue,
                          hipStream_t stream, const RopeArgs* ra = nullptr, const void* Wp = nullptr,
-                         const float* wscale = nullptr) {
+                         const float* wscale = nullptr, const TailNorm* tn = nullptr) {
     if (!X || !W || (!out && !ra) || M < 0 || N <= 0 || K <= 0) return O3V_ERR_ARG;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || M > 32 || (M > 16 && norm_w)) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
@@ -1052,12 +1096,13 @@ static int gemv_dispatch(const void* X, const void* W, const void* bias, const v
     }
     if (M >= 4 && (K % 32) == 0 && (N % 16) == 0 && (epilogue != EPI_QKVROPE || (a.ra.D % 32) == 0) &&
         (epilogue != EPI_SWIGLU || (N % 32) == 0) && (!a.packed || (N % 16 == 0)) && (!norm_w || (size_t)M * (K * 2 + 16) <= 144 * 1024)) {
+        if (tn) a.tn = *tn;
         int rcm = launch_gemv_mfma(a, M);
         if (rcm != O3V_OK) return rcm;
         O3V_CHECK_LAUNCH();
         return O3V_OK;
     }
-    if (M > 8) return O3V_ERR_SHAPE;  // 9..32 rows exist only on the matrix-core path (one or two MFMA column blocks)
+    if (M > 8 || tn) return O3V_ERR_SHAPE;  // 9..32 rows (and the TailNorm) exist only on the matrix-core path (one or two MFMA column blocks)
     a.W = (const bf16_t*)W;  // scalar path reads the row-major image
     a.packed = false;
     int rc;
@@ -1102,6 +1147,32 @@ extern "C" int o3v_linear_decode(const void* X, const void* norm_w, float eps, c
                                  const void* bias, const void* res, void* out, int M, int N, int K, int ldx, int ldo,
                                  int ldr, int epilogue, hipStream_t stream) {
     return gemv_dispatch(X, W, bias, res, out, norm_w, eps, M, N, K, ldx, K, ldo, ldr, epilogue, stream, nullptr, Wp);
+}
+
+// out = X . W^T + res AND h = RMSNorm(out; next_norm_w) for the linear that follows, 8..32 rows of already normalised X on the
+// fragment-major image Wp: one launch instead of the residual linear + o3v_rmsnorm (TailNorm above; h is bit-identical to
+// o3v_rmsnorm(out)).  `sync`: the zeroed buffer of o3v_decode_sync_bytes(); `epoch` = 1, 2, ... counts the calls that share it.
+// O3V_ERR_SHAPE when the form does not apply (the caller then issues the two launches).
+extern "C" int o3v_linear_decode_norm_next(const void* X, const void* Wp, const void* res, void* out, int M, int N, int K, int ldx,
+                                           int ldo, int ldr, const void* next_norm_w, float eps, void* h, int ldh, uint32_t* sync,
+                                           uint32_t epoch, hipStream_t stream) {
+    if (!X || !Wp || !res || !out || !next_norm_w || !h || !sync || epoch == 0) return O3V_ERR_ARG;
+    if (M < 8 || M > 32 || N > 4096 || (N & 15) || (ldh & 7) || (ldo & 7)) return O3V_ERR_SHAPE;
+    static const bool gfx950 = [] {  // the hand-off rests on measured gfx950 behaviour (o3v_handoff.h)
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }();
+    if (!gfx950) return O3V_ERR_SHAPE;
+    TailNorm tn;
+    tn.sync = sync;
+    tn.epoch = epoch;
+    tn.w = (const bf16_t*)next_norm_w;
+    tn.h = (bf16_t*)h;
+    tn.ldh = ldh;
+    tn.eps = eps;
+    return gemv_dispatch(X, Wp, nullptr, res, out, nullptr, 0.f, M, N, K, ldx, K, ldo, ldr, EPI_RESIDUAL, stream, nullptr, Wp, nullptr, &tn);
 }
 
 // Decode q/k/v projection with everything around it fused: RMSNorm prologue, bias, M-RoPE, q written to qout[M,Hq,D],

@@ -32,6 +32,11 @@ constexpr uint32_t O3V_SPIN_LIMIT = 1u << 16;  // polls of ~0.5-1 us each: a wai
 
 #define O3V_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// lines of the sync buffer used outside o3v_fused.hip (its own lines: 0..18, 24.. -- see the SYNC_* constants there)
+constexpr int O3V_SYNC_TMO_WORD = 16 * O3V_SYNC_STRIDE;     // sticky time-out word (byte 2048 = O3V_SYNC_TMO_BYTE)
+constexpr int O3V_SYNC_TAIL_TICKET = 19 * O3V_SYNC_STRIDE;  // TailNorm (o3v_gemm.hip): tickets of the storing waves
+constexpr int O3V_SYNC_TAIL_DONE = 20 * O3V_SYNC_STRIDE;    // TailNorm: epoch whose rows are all in memory
+
 // wave-uniform: true once lanes 0..n-1 all read `want` from p[lane] (n <= 64 words of ONE mailbox line)
 template <int SLEEP>
 __device__ __forceinline__ bool spin_until(uint32_t* p, int n, uint32_t want, uint32_t* tmo, uint32_t code) {

@@ -74,6 +74,11 @@ class O3VEngine:
         # workgroups) is bit-identical but measured SLOWER than the role block + gate/up launch (95.3 vs 90.3 us per layer at 7B,
         # profiles/r03_layer_block_timeline_v2.txt): off unless O3V_LAYER_BLOCK=1
         self.layer_block = os.environ.get("O3V_LAYER_BLOCK", "0") == "1"
+        # 8..32 decode rows: o_proj / down_proj can also normalise their result for the linear that follows (o3v_linear_decode_norm_next,
+        # bit-identical to the separate o3v_rmsnorm launch it replaces).  Measured equal, not faster (G=8 3.765 vs 3.760 ms/step, G=16
+        # 4.324 vs 4.321: the in-launch chain store-ack -> ticket -> poll -> row load costs the residual linear +6.4 us, the launch it
+        # removes 5.9 us; profiles/r03_tail_norm_ab.txt): off unless O3V_TAIL_NORM=1
+        self.tail_norm = os.environ.get("O3V_TAIL_NORM", "0") == "1"
         # video rope arithmetic (indexing.rope_index): "tf5" = transformers 5.15 (goldens G5b / G14 / G15), "pinned" = the
         # libraries the reference installs (transformers @336dc69d, vllm 0.7.2).  The facades choose; images do not depend on it.
         self.position_mode = "tf5"
@@ -496,7 +501,8 @@ class O3VEngine:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         # tickets / mailboxes of the one-launch attention block (batch 1): zeroed once per call, epochs count the launches
         sync = None
-        if self.fused_decode and _fused_ok and B == 1:
+        # (8..32 rows: the residual linears of the batched decode normalise for the next linear through the same buffer)
+        if self.fused_decode and _fused_ok and (B == 1 or (B >= 8 and self.tail_norm)):
             sync = torch.zeros(_lib.load().o3v_decode_sync_bytes(), dtype=torch.uint8, device=self.dev)
             if getattr(self, "_debug_poison_sync", False):     # test hook: tickets that can never reach "last" -> the waits give up
                 sync[:1024].view(torch.int32).fill_(0x40000000)
@@ -515,7 +521,7 @@ class O3VEngine:
                               rows_per_prompt=G if shared_prompt else 0)
         stats = (C.c_longlong * 4)(0, 0, 0, 0)      # decode forwards, launches in their layer loops, fused / stand-alone attention halves
         st.host_stats = C.cast(stats, C.c_void_p)
-        st.flags = 1 if self.layer_block else 0
+        st.flags = (1 if self.layer_block else 0) | (0 if self.tail_norm else 2)
         tm["kv_cache_bytes"] = int((kc.numel() + vc.numel() + (kc0.numel() + vc0.numel() if shared_prompt else 0)) * 2)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0

@@ -1385,3 +1385,58 @@ def test_fused_rmsnorm_does_not_depend_on_the_decomposition(dev):
         _lib.call("o3v_linear_decode", P(x), P(nw), 1e-6, P(w), None, None, None, P(o1), 1, N1, K, K, N1, 0, _lib.EPI_NONE, st)
         _lib.call("o3v_linear_decode", P(x), P(nw), 1e-6, P(w), None, None, None, P(o2), 1, N2, K, K, N2, 0, _lib.EPI_NONE, st)
         assert torch.equal(o1[:, :N2].view(torch.int16), o2.view(torch.int16)), trial
+
+
+@pytest.mark.parametrize("M", [8, 11, 16, 24, 32])
+@pytest.mark.parametrize("N,K", [(3584, 3584), (3584, 18944), (2048, 11008), (4096, 12288), (896, 4864)])
+def test_linear_decode_norm_next_equals_linear_plus_rmsnorm(dev, M, N, K):
+    """o3v_linear_decode_norm_next (residual linear whose last M storing waves normalise one row each for the NEXT linear) ==
+    o3v_linear_decode(RESIDUAL) + o3v_rmsnorm BIT FOR BIT, residual stream in place, four epochs on one sync buffer, no wait
+    gave up.  Shapes: o_proj / down_proj of the 7B, 3B and 8B classes and of the medium fixture."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    g = torch.Generator().manual_seed(N + K + M)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wp = pack_mfma_fragments(w)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    lib = _lib.load()
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h2 = torch.zeros(M, N, dtype=BF, device=dev)
+    for epoch in range(1, 5):
+        a = torch.randn(M, K, generator=g).to(BF).to(dev)
+        x0 = (torch.randn(M, N, generator=g) * 2).to(BF).to(dev)
+        x1, x2 = x0.clone(), x0.clone()
+        h1 = torch.zeros(M, N, dtype=BF, device=dev)
+        _lib.call("o3v_linear_decode", P(a), None, 0.0, P(w), P(wp), None, P(x1), P(x1), M, N, K, K, N, N, _lib.EPI_RESIDUAL, st)
+        _lib.call("o3v_rmsnorm", P(x1), P(nw), P(h1), M, N, N, N, 1e-6, st)
+        h2.fill_(float("nan"))
+        rc = lib.o3v_linear_decode_norm_next(P(a), P(wp), P(x2), P(x2), M, N, K, K, N, N, P(nw), 1e-6, P(h2), N, P(sync), epoch, st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        tmo = int(sync[_lib.SYNC_TMO_BYTE:_lib.SYNC_TMO_BYTE + 4].view(torch.int32)[0].item())
+        assert tmo == 0, f"a wait gave up (code {tmo:#x})"
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16))
+        assert torch.equal(h2.view(torch.int16), h1.view(torch.int16)), (epoch, (h2.float() - h1.float()).abs().max().item())
+
+
+def test_linear_decode_norm_next_rejects(dev):
+    """Shapes the form does not take return O3V_ERR_SHAPE / O3V_ERR_ARG before any launch (the engine then issues two launches)."""
+    import ctypes as C
+    from open_o3_video_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(32 * 8192, dtype=BF, device=dev)
+    sync = torch.zeros(lib.o3v_decode_sync_bytes(), dtype=torch.uint8, device=dev)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda M, N, K, ep, sy: lib.o3v_linear_decode_norm_next(P(t), P(t), P(t), P(t), M, N, K, K, N, N, P(t), 1e-6, P(t), N, sy, ep, st)
+    assert call(4, 3584, 3584, 1, P(sync)) == _lib.ERR_SHAPE          # fewer than 8 rows: the fused-norm linears
+    assert call(33, 3584, 3584, 1, P(sync)) == _lib.ERR_SHAPE
+    assert call(8, 8192, 1024, 1, P(sync)) == _lib.ERR_SHAPE          # rows longer than a wave normalises from registers
+    assert call(16, 128, 1024, 1, P(sync)) == _lib.ERR_SHAPE          # fewer storing waves than rows
+    assert call(8, 3584, 3584, 0, P(sync)) == _lib.ERR_ARG            # epochs start at 1
+    assert call(8, 3584, 3584, 1, None) == _lib.ERR_ARG
+    torch.cuda.synchronize()
+    assert int(sync.view(torch.int32).abs().sum().item()) == 0

@@ -519,3 +519,32 @@ def test_in_launch_wait_give_up_reruns_on_stand_alone_kernels(need_gpu, golden_d
     again = eng.generate(g["input_ids"], None, **kw)
     assert again.timings["fused_attention_layers"] > 0 and eng.fused_fallbacks == 1
     assert torch.equal(again.sequences, ok.sequences)
+
+
+def test_batched_rows_tail_norm_equals_separate_norm_launches(need_gpu):
+    """8..32 decode rows: o_proj / down_proj normalise their result for the next linear inside their own launch
+    (o3v_linear_decode_norm_next).  The ids and margins are bit-identical to the run with the separate o3v_rmsnorm launches
+    (engine.tail_norm = False), for independent rows and for a sampled group, and the engine reports two launches fewer per layer (all but layer 0's first norm)."""
+    cfg = fm.medium_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 2))
+    eng.tail_norm = True        # opt-in (measured equal to the separate launches, profiles/r03_tail_norm_ab.txt)
+    fr = fm.make_frames(2, 56, 84, seed=8)
+    _, grid = eng.pixels_from_frames(fr)
+    ids = fm.make_prompt(cfg, [tuple(r) for r in grid.tolist()], seed=8)
+    cases = [dict(prompts=[ids] * 9, frames=torch.cat([fr] * 9), kw=dict(max_new_tokens=20)),
+             dict(prompts=[ids], frames=fr, kw=dict(max_new_tokens=20, num_return_sequences=16, do_sample=True, top_p=0.95, top_k=50,
+                                                    temperature=1.0, seed=11)),
+             dict(prompts=[ids], frames=fr, kw=dict(max_new_tokens=12, num_return_sequences=32, do_sample=True, top_p=0.9,
+                                                    temperature=1.0, seed=12))]
+    for c in cases:
+        a = eng.generate(c["prompts"], None, frames=c["frames"], **c["kw"])
+        try:
+            eng.tail_norm = False
+            b = eng.generate(c["prompts"], None, frames=c["frames"], **c["kw"])
+        finally:
+            eng.tail_norm = True
+        assert torch.equal(a.sequences, b.sequences)
+        assert a.margins is None or torch.equal(a.margins, b.margins)
+        la, lb = a.timings["launches_per_layer"], b.timings["launches_per_layer"]
+        L = eng.cfg.text.num_hidden_layers      # only layer 0's first norm of a step stays a launch of its own
+        assert abs((lb - la) - (2 - 1 / L)) < 1e-6, (la, lb)
