@@ -474,6 +474,10 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
     // at B=8, 75 -> 50 us at B=16 (profiles/r01_m8_linear.txt).  Whole step, 7B: B=4 3.56 -> 3.61 ms (worse: two more
     // launches per layer), B=8 4.04 -> 3.97, B=16 5.63 -> 5.25: taken from B=8 on.
     const bool norm_apart = B >= 8;
+    // ... except q/k/v at 8 rows: its grid is ~1 workgroup per CU (288 at 7B), so the LDS the fused norm stages x in costs no
+    // residency, and the prologue replaces a 5.9 us launch.  Same sums, same rounding as o3v_rmsnorm: bit-identical.  Measured
+    // (7B, G rows of one prompt, ms/step fused | apart): G=8 3.721 | 3.768, G=16 4.365 | 4.312 -- taken at 8 rows only.
+    const bool qkv_fused_norm = norm_apart && B <= 8 && !(st->flags & 4) && (size_t)B * (H * 2 + 16) <= 144 * 1024;
     // batch 1: q/k/v + attention + merge + o_proj as ONE launch (o3v_fused.hip); epoch = index of the launch in this generate call
     // fp8 weights (batch <= 3): every decode linear streams the fp8 copy
     const bool fp8 = B <= 3 && d->layer[0].qkv_w8 && d->layer[0].o_w8 && d->layer[0].gu_w8 && d->layer[0].down_w8 && st->group <= 1;
@@ -506,7 +510,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
             else if (fp8b && lw.qkv_w8p) {
                 TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode_fp8_rows(w.h, lw.qkv_w8p, lw.qkv_s, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
-            } else if (norm_apart) {  // (above 16 rows the linears take no fused norm at all)
+            } else if (norm_apart && !qkv_fused_norm) {  // (above 16 rows the linears take no fused norm at all)
                 if (!h_ready) TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
                 TRY(o3v_linear_decode(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, nullptr, w.qkv, B, NQKV, H, H, NQKV, 0, O3V_EPI_NONE, s));
             } else
@@ -521,7 +525,7 @@ extern "C" int o3v_llm_decode(const o3v_llm_desc* d, const o3v_decode_state* st,
         } else if (fp8) {
             TRY(o3v_gemv_norm_qkv_rope_fp8(st->x, lw.ln1, d->rms_eps, lw.qkv_w8, lw.qkv_s, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q,
                                            kc, vc, slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));
-        } else if (norm_apart) {
+        } else if (norm_apart && !qkv_fused_norm) {
             if (!h_ready) TRY(o3v_rmsnorm(st->x, lw.ln1, w.h, B, H, H, H, d->rms_eps, s));
             TRY(o3v_gemv_norm_qkv_rope(w.h, nullptr, 0.f, lw.qkv_w, lw.qkv_wp, lw.qkv_b, B, H, H, st->cosT, st->sinT, w.q, kc, vc,
                                        slot0 + step, Hq, Hkv, D, st->Tmax, st->Tnew, step, s));

@@ -521,7 +521,7 @@ class O3VEngine:
                               rows_per_prompt=G if shared_prompt else 0)
         stats = (C.c_longlong * 4)(0, 0, 0, 0)      # decode forwards, launches in their layer loops, fused / stand-alone attention halves
         st.host_stats = C.cast(stats, C.c_void_p)
-        st.flags = (1 if self.layer_block else 0) | (0 if self.tail_norm else 2)
+        st.flags = (1 if self.layer_block else 0) | (0 if self.tail_norm else 2) | (4 if os.environ.get("O3V_QKV_FUSED_NORM", "1") == "0" else 0)
         tm["kv_cache_bytes"] = int((kc.numel() + vc.numel() + (kc0.numel() + vc0.numel() if shared_prompt else 0)) * 2)
         # ---- decode loop: chunks of steps enqueued from C++, one host check per chunk (TF:utils.py:2936-2937)
         done = 0

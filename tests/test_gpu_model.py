@@ -532,6 +532,7 @@ def test_batched_rows_tail_norm_equals_separate_norm_launches(need_gpu):
     _, grid = eng.pixels_from_frames(fr)
     ids = fm.make_prompt(cfg, [tuple(r) for r in grid.tolist()], seed=8)
     cases = [dict(prompts=[ids] * 9, frames=torch.cat([fr] * 9), kw=dict(max_new_tokens=20)),
+             dict(prompts=[ids] * 8, frames=torch.cat([fr] * 8), kw=dict(max_new_tokens=20)),
              dict(prompts=[ids], frames=fr, kw=dict(max_new_tokens=20, num_return_sequences=16, do_sample=True, top_p=0.95, top_k=50,
                                                     temperature=1.0, seed=11)),
              dict(prompts=[ids], frames=fr, kw=dict(max_new_tokens=12, num_return_sequences=32, do_sample=True, top_p=0.9,
@@ -547,4 +548,5 @@ def test_batched_rows_tail_norm_equals_separate_norm_launches(need_gpu):
         assert a.margins is None or torch.equal(a.margins, b.margins)
         la, lb = a.timings["launches_per_layer"], b.timings["launches_per_layer"]
         L = eng.cfg.text.num_hidden_layers      # only layer 0's first norm of a step stays a launch of its own
-        assert abs((lb - la) - (2 - 1 / L)) < 1e-6, (la, lb)
+        rows = a.sequences.shape[0]             # (at 8 rows q/k/v carries its norm fused in either run: one launch fewer, not two)
+        assert abs((lb - la) - (1 if rows <= 8 else 2 - 1 / L)) < 1e-6, (la, lb)
