@@ -66,7 +66,13 @@ class O3VEngine:
         self.clip_std = (C.c_float * 3)(*((0.5, 0.5, 0.5) if self.q3 else CLIP_STD))
         self._vit_plan_cache = {}
         self._prefix = {}   # prefix_key -> {"ids", "k", "v"}: prompt K/V kept for reuse (see generate(prefix_key=...))
-        import os
+        # The prompt of the last group generate (num_return_sequences > 1): its K/V, kept once anyway, and the hidden row that predicts
+        # completion token 0.  The policy's log-prob pass over those completions (completion_logps, R:grpo_trainer.py:612-613) finds the
+        # SAME prompt -- ids, mask, grids, positions and visual tensors equal bit for bit (_prompt_key) -- and skips the tower and the
+        # prompt prefill; anything else (another model, a video whose second_per_grid_ts the trainer deleted) recomputes.
+        self.reuse_prompt_kv = os.environ.get("O3V_REUSE_PROMPT_KV", "1") != "0"
+        self._last_prompt = None
+        self.timings_last_logps = {}
         self.group_attention = os.environ.get("O3V_GROUP_ATTENTION", "1") != "0"   # A/B switch for the shared-prefix kernel
         self.fused_decode = os.environ.get("O3V_FUSED_DECODE", "1") != "0"         # A/B switch for the one-launch attention block
         self.group_attention_mode = os.environ.get("O3V_GROUP_MODE", "auto")
@@ -244,6 +250,27 @@ class O3VEngine:
         s = torch.from_numpy(src).to(self.dev)
         _lib.call("o3v_embed_scatter", _ptr(self.w.t["l.embed"]), _ptr(vis), _ptr(s), _ptr(x), T, H, _stream())
         return x
+
+    def _prompt_key(self, ids, mask, pos, tensors):
+        """Identity of a prompt for the generate -> log-prob hand-over: token ids, mask and rope positions as bytes, every visual input
+        by shape, dtype and two 64-bit checksums of its bytes (a plain sum and a position-weighted one, computed where the tensor
+        lives)."""
+        parts = [ids.tobytes(), mask.tobytes(), pos.tobytes(), self.position_mode]
+        for name, t in tensors:
+            if t is None:
+                parts.append((name, None))
+                continue
+            if isinstance(t, (list, tuple)):
+                t = torch.cat([torch.as_tensor(u).reshape(-1).view(torch.uint8) for u in t])
+            t = torch.as_tensor(t)
+            raw = t.detach().contiguous().reshape(-1).view(torch.uint8)
+            pad = (-raw.numel()) % 4
+            if pad:
+                raw = torch.cat([raw, raw.new_zeros(pad)])
+            w = raw.view(torch.int32).to(torch.int64)
+            wt = (torch.arange(w.numel(), device=w.device, dtype=torch.int64) & 0xFFFF) + 1
+            parts.append((name, tuple(t.shape), str(t.dtype), int(w.sum().item()), int((w * wt).sum().item())))
+        return tuple(parts)
 
     def _visual(self, pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw, video_frames):
         """The visual side of a call -> (vis, image grid, video grid, n_image_rows): image tokens first, video tokens after them
@@ -440,6 +467,12 @@ class O3VEngine:
             if not shared_prompt:
                 kc0 = vc0 = None
         tm["prefix_tokens_reused"] = past
+        self._last_prompt = None
+        if self.reuse_prompt_kv and shared_prompt and B0 == 1:
+            key = self._prompt_key(ids, mask, pos, (("pv", pixel_values), ("grid", grid), ("frames", frames), ("vis", vis_embeds),
+                                                    ("pvv", pixel_values_videos), ("vgrid", vgrid), ("vframes", video_frames)))
+            self._last_prompt = {"key": key, "kc0": kc0, "vc0": vc0, "x_last": x.view(B0, S - past, -1)[0, -1:, :].clone(),
+                                 "deltas": np.array(deltas, copy=True)}
         last = x.view(B0, S - past, -1)[:, -1, :]               # left padding: every row ends at S-1
         logits0 = self.head(last)                               # [B0, V]
         logits = logits0.repeat_interleave(G, dim=0).contiguous() if G > 1 else logits0
@@ -647,19 +680,41 @@ class O3VEngine:
         pad = (mask == 0).sum(axis=1)
         if not (mask[0, pad[0]:] == 1).all():
             raise ValueError("only left padding is supported (padding_side='left', R:grpo_trainer.py:546)")
-        vis, grid, vgrid, n_img_rows = self._visual(pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos, video_grid_thw,
-                                                    video_frames)
-        pos, deltas = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
         H = tc.hidden_size
         out = torch.empty((G, T), dtype=torch.float32, device=self.dev)
         if T == 0 or G == 0:
             return out
-        # prompt once
-        kc0, vc0 = self.alloc_cache(1, S)
-        x = self.embed(ids, vis, n_image_rows=n_img_rows)
-        self.prefill(x, pos, pad, 1, S, kc0, vc0, deepstack=(ids, vis) if self.q3 else None)
-        x_last = x[S - 1:S].clone()                               # hidden state that predicts completion token 0
-        del x
+        as_np = lambda g: None if g is None else np.asarray(g.cpu() if torch.is_tensor(g) else g, dtype=np.int64).reshape(-1, 3)
+        grid, vgrid = as_np(image_grid_thw), as_np(video_grid_thw)
+        if frames is not None:
+            ps = cfg.vision.patch_size
+            grid = np.asarray([[1, frames.shape[2] // ps, frames.shape[3] // ps]] * frames.shape[0], dtype=np.int64)
+        if video_frames is not None:
+            vgrid = None      # derived from the frames by the tower's front end: no hand-over for this input form
+        memo, self.timings_last_logps = self._last_prompt, {"prompt_kv_reused": False}
+        pos = deltas = None
+        if memo is not None and (video_frames is None):
+            pos, deltas = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
+            key = self._prompt_key(ids, mask, pos, (("pv", pixel_values), ("grid", grid), ("frames", frames), ("vis", vis_embeds),
+                                                    ("pvv", pixel_values_videos), ("vgrid", vgrid), ("vframes", video_frames)))
+            if key != memo["key"]:
+                memo = None
+        else:
+            memo = None
+        if memo is not None:
+            # the prompt generate has just prefilled: same bytes in, same kernels -> the K/V and the last hidden row it kept
+            kc0, vc0, x_last, deltas = memo["kc0"], memo["vc0"], memo["x_last"], memo["deltas"]
+            self.timings_last_logps["prompt_kv_reused"] = True
+        else:
+            vis, grid, vgrid, n_img_rows = self._visual(pixel_values, image_grid_thw, frames, vis_embeds, pixel_values_videos,
+                                                        video_grid_thw, video_frames)
+            pos, deltas = self._positions(ids, mask, grid, vgrid, second_per_grid_ts)
+            # prompt once
+            kc0, vc0 = self.alloc_cache(1, S)
+            x = self.embed(ids, vis, n_image_rows=n_img_rows)
+            self.prefill(x, pos, pad, 1, S, kc0, vc0, deepstack=(ids, vis) if self.q3 else None)
+            x_last = x[S - 1:S].clone()                               # hidden state that predicts completion token 0
+            del x
         rows = torch.empty((G, T, H), dtype=torch.bfloat16, device=self.dev)
         rows[:, 0] = x_last
         if T > 1:

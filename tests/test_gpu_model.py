@@ -550,3 +550,37 @@ def test_batched_rows_tail_norm_equals_separate_norm_launches(need_gpu):
         L = eng.cfg.text.num_hidden_layers      # only layer 0's first norm of a step stays a launch of its own
         rows = a.sequences.shape[0]             # (at 8 rows q/k/v carries its norm fused in either run: one launch fewer, not two)
         assert abs((lb - la) - (1 if rows <= 8 else 2 - 1 / L)) < 1e-6, (la, lb)
+
+
+def test_policy_logps_reuse_the_prompt_generate_prefilled(need_gpu):
+    """completion_logps right after the group generate of the same prompt takes the prompt's K/V and last hidden row from that call
+    (no tower pass, no prompt prefill) and returns the same bits as the pass that recomputes them; a changed pixel, a changed token
+    or another mask is a different prompt and recomputes."""
+    cfg = fm.medium_config()
+    eng = build_engine(cfg, fm.make_weights(cfg, 2))
+    fr = fm.make_frames(2, 56, 84, seed=9)
+    _, grid = eng.pixels_from_frames(fr)
+    ids = fm.make_prompt(cfg, [tuple(r) for r in grid.tolist()], seed=9)
+    kw = dict(max_new_tokens=10, num_return_sequences=4, do_sample=True, top_p=0.95, top_k=50, temperature=1.0, seed=3)
+    out = eng.generate([ids], None, frames=fr, **kw)
+    comp = out.sequences[:, len(ids):]
+    a = eng.completion_logps([ids], comp, frames=fr)
+    assert eng.timings_last_logps["prompt_kv_reused"]
+    eng.reuse_prompt_kv, keep = False, eng._last_prompt
+    eng._last_prompt = None
+    b = eng.completion_logps([ids], comp, frames=fr)
+    assert not eng.timings_last_logps["prompt_kv_reused"]
+    assert torch.equal(a, b)
+    eng.reuse_prompt_kv, eng._last_prompt = True, keep
+    fr2 = fr.clone()
+    fr2[1, 2, 17, 33] ^= 1                                       # one bit of one pixel
+    c = eng.completion_logps([ids], comp, frames=fr2)
+    assert not eng.timings_last_logps["prompt_kv_reused"]
+    ids2 = list(ids)
+    ids2[-1] = (ids2[-1] + 1) % 1000 + 5
+    eng.completion_logps([ids2], comp, frames=fr)
+    assert not eng.timings_last_logps["prompt_kv_reused"]
+    # a generate without a group keeps nothing
+    eng.generate([ids], None, frames=fr, max_new_tokens=4)
+    eng.completion_logps([ids], comp, frames=fr)
+    assert not eng.timings_last_logps["prompt_kv_reused"]
