@@ -107,6 +107,12 @@ int o3v_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
  * kernels give bit-identical results).  The model-level entries take the choice from their descriptor's gemm_tile. */
 int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
                        int ldw, int ldo, int ldr, int epilogue, int tile, o3v_stream_t stream);
+/* The 256 x 256 x 64 tile on the PHASED schedule (csrc/o3v_gemm8p.hip): 16-MFMA phases between raw barriers, the global->LDS copies
+ * of half-tiles kept 6 deep in flight across them (counted vmcnt), the two wave rows one barrier apart so that a SIMD always has
+ * one wave multiplying while the other reads LDS.  K % 128 == 0, K >= 256; bit-identical to o3v_gemm_bf16 / o3v_gemm_bf16_tile;
+ * O3V_ERR_SHAPE otherwise.  o3v_gemm_bf16 picks it by itself where it applies. */
+int o3v_gemm_bf16_phased(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K, int lda,
+                         int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
 /* o3v_gemm_bf16 for row counts too small to fill the chip with 128x128 output tiles (a prompt suffix behind a cached
  * prefix: 9..128 rows): K split over `splits` blocks per tile, fp32 partials in `workspace` (splits*M*N floats), reduced
  * in split order.  Epilogues NONE / RESIDUAL / GELU. */

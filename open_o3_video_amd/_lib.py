@@ -99,6 +99,7 @@ SIGNATURES = {
     "o3v_attn_tiles": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp],
     "o3v_attn_decode": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "o3v_gemm_bf16_tile": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_gemm_bf16_phased": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_gemm_bf16_splitk": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp],
     "o3v_resize_bicubic_aa": [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp],
     "o3v_crop_resize_bilinear": [vp, vp, vp, i32, i32, i32, i32, vp],

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libo3v_hip.so")
-SOURCES = ["o3v_elem.hip", "o3v_gemm.hip", "o3v_fp8.hip", "o3v_attn.hip", "o3v_fused.hip", "o3v_sample.hip", "o3v_engine.hip"]
+SOURCES = ["o3v_elem.hip", "o3v_gemm.hip", "o3v_gemm8p.hip", "o3v_fp8.hip", "o3v_attn.hip", "o3v_fused.hip", "o3v_sample.hip", "o3v_engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 

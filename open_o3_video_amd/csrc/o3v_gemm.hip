@@ -13,6 +13,7 @@
 // makes every ds_read_b128 lane-group conflict-free on the 128-byte tile rows.  Two LDS buffers, one
 // barrier per K-tile (the stage of tile t+1 is issued before the MFMAs of tile t).
 #include <cstring>
+#include "../../include/o3v.h"
 #include "o3v_common.h"
 #include "o3v_gemv_body.h"
 
@@ -908,10 +909,11 @@ extern "C" int o3v_gemm_bf16_splitk(const void* A, const void* W, const void* bi
 // fraction of the chip's block slots a grid of `tiles` blocks keeps busy over its ceil(tiles/slots) rounds
 static inline float fill_eff(int tiles, int slots) { return (float)tiles / (float)(((tiles + slots - 1) / slots) * slots); }
 
-// tile: 0 = choose per shape, 128 / 256 = force that kernel (tests, A/B measurements; both give bit-identical results)
+// tile: 0 = choose per shape, 128 / 256 / 257 = force the 128-tile kernel, the 256-tile kernel with one __syncthreads() per K-step,
+// the phased 256-tile kernel of o3v_gemm8p.hip (tests, A/B measurements; all give bit-identical results)
 extern "C" int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                                   int lda, int ldw, int ldo, int ldr, int epilogue, int tile, hipStream_t stream) {
-    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || (tile != 0 && tile != 128 && tile != 256)) return O3V_ERR_ARG;
+    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || (tile != 0 && tile != 128 && tile != 256 && tile != 257)) return O3V_ERR_ARG;
     if ((K % BK) || (lda & 7) || (ldw & 7)) return O3V_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && !res) return O3V_ERR_ARG;
     if (epilogue == EPI_SWIGLU && (N % 32)) return O3V_ERR_SHAPE;
@@ -919,10 +921,16 @@ extern "C" int o3v_gemm_bf16_tile(const void* A, const void* W, const void* bias
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int t2m = (M + BM2 - 1) / BM2, t2n = (N + BM2 - 1) / BM2;
     // 256-tiles: one block per CU (256 slots), more padding at ragged edges; 128-tiles: two blocks per CU (512 slots)
-    constexpr float O3V_GEMM256_GAIN = 1.3f;  // full-grid speed ratio of the two kernels (profiles/r01_gemm_tile_ab.txt)
+    // full-grid speed ratio of the 256-tile kernels over the 128-tile one: 1.3 for the kernel with one __syncthreads() per K-step
+    // (profiles/r01_gemm_tile_ab.txt), 1.55 for the phased schedule of o3v_gemm8p.hip, which needs an even number of K-tiles
+    // (profiles/r03_gemm_phased.txt)
+    const bool can_phase = (K % (2 * BK)) == 0 && K >= 4 * BK && tile != 256;
+    const float gain256 = can_phase ? 1.55f : 1.3f;
     const float use128 = fill_eff(tiles_m * tiles_n, 512) * ((float)M * N / ((float)tiles_m * BM * (float)tiles_n * BN));
-    const float use256 = O3V_GEMM256_GAIN * fill_eff(t2m * t2n, 256) * ((float)M * N / ((float)t2m * BM2 * (float)t2n * BM2));
-    const bool big = tile ? tile == 256 : (M >= 1024 && N >= 1024 && use256 > use128);
+    const float use256 = gain256 * fill_eff(t2m * t2n, 256) * ((float)M * N / ((float)t2m * BM2 * (float)t2n * BM2));
+    const bool big = tile ? tile >= 256 : (M >= 1024 && N >= 1024 && use256 > use128);
+    if (big && can_phase) return o3v_gemm_bf16_phased(A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldr, epilogue, stream);
+    if (tile == 257) return O3V_ERR_SHAPE;  // the phased kernel was asked for and does not take this K
     if (big) {
         dim3 grid(t2m * t2n), block(512);
         const size_t shmem = 8 * 64 * 68 * 4;  // max(2 stages x (A + B) = 128 KiB, epilogue staging 8 waves x 64 x 68 f32)

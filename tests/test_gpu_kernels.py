@@ -1440,3 +1440,40 @@ def test_linear_decode_norm_next_rejects(dev):
     assert call(8, 3584, 3584, 1, None) == _lib.ERR_ARG
     torch.cuda.synchronize()
     assert int(sync.view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (700, 1280, 384), (515, 3456, 1280), (1030, 520, 256), (300, 4608, 3584),
+                                   (4490, 3584, 3584), (2049, 1288, 1152), (4490, 3584, 18944), (9, 256, 512)])
+def test_gemm_phased_kernel(dev, M, N, K):
+    """The phased 256-tile kernel (csrc/o3v_gemm8p.hip: 16-MFMA phases between raw barriers, half-tile copies 6 deep in flight, the
+    two wave rows one barrier apart) is BIT-IDENTICAL to the kernel with one __syncthreads() per K-step for every epilogue, at ragged
+    M / N edges, short and long K (4 to 296 K-tiles) -- and stays so over repeated launches with other kernels in between (a misplaced
+    wait or a too-early re-stage shows as rare wrong tiles, not as a constant error)."""
+    import kernel_ops as ops
+    from open_o3_video_amd.weights import pack_gate_up
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    cases = [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, bias, res), (ops.EPI_GELU, None, None)]
+    ref = [ops.gemm(a, w, b, r, epi, force="gemm", tile=256) for epi, b, r in cases]
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for rep in range(6):
+        for (epi, b, r), want in zip(cases, ref):
+            got = ops.gemm(a, w, b, r, epi, force="gemm", tile=257)
+            junk.fill_(rep)                                   # other traffic between the launches
+            assert torch.equal(got, want), (rep, epi, int((got != want).sum()))
+    if N % 32 == 0:
+        I = N // 2
+        packed = pack_gate_up(w[:I].contiguous(), w[I:].contiguous(), I)
+        want = ops.gemm(a, packed, None, None, ops.EPI_SWIGLU, force="gemm", tile=256)
+        for rep in range(3):
+            assert torch.equal(ops.gemm(a, packed, None, None, ops.EPI_SWIGLU, force="gemm", tile=257), want)
+    # an odd number of K-tiles is not taken
+    from open_o3_video_amd import _lib
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    o = torch.empty(M, N, dtype=BF, device=dev)
+    assert _lib.load().o3v_gemm_bf16_phased(P(a), P(w), None, None, P(o), M, N, 192, K, K, N, 0, 0, st) == _lib.ERR_SHAPE
