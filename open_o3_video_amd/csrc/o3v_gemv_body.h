@@ -200,6 +200,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
         // none.  So rstd, and with it every normalised element, does not depend on the decomposition the launcher picked
         // (or on which kernel -- stand-alone, one-launch block, norm_finish of the layer block -- computes it).
         constexpr int VW = (4 + NW - 1) / NW;        // virtual waves per real wave (at most)
+        constexpr bool ALLV = (4 % NW) == 0;         // 1, 2, 4 waves: every (wave, v) is one of the four virtual waves
         constexpr int XC = 2;                        // chunks per virtual thread kept in registers (K <= 4096)
         const bool small = (nxc <= XC * 256) && (M <= 4);
         u32x4 xr[VW][XC][M <= 4 ? M : 1], wnr[VW][XC];  // x chunks and the norm-weight chunks that go with them: one latency, not two
@@ -215,7 +216,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 for (int i = 0; i < XC; ++i) {
                     const int vw = wave + v * NW;
                     const int c = vw * 64 + lane + i * 256;
-                    const bool in = vw < 4 && c < nxc;
+                    const bool in = (ALLV || vw < 4) && c < nxc;
 #pragma unroll
                     for (int m = 0; m < (M <= 4 ? M : 1); ++m)
                         xr[v][i][m] = in ? *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8) : (u32x4){0, 0, 0, 0};
@@ -239,7 +240,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
             for (int v = 0; v < VW; ++v) {
                 const int vw = wave + v * NW;
-                for (int c = vw * 64 + lane; vw < 4 && c < nxc; c += 256) {
+                for (int c = vw * 64 + lane; (ALLV || vw < 4) && c < nxc; c += 256) {
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const u32x4 xv4 = *reinterpret_cast<const u32x4*>(X + (size_t)m * ldx + (size_t)c * 8);
@@ -259,7 +260,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 ss[v][m] = wave_sum(ss[v][m]);
-                if (lane == 0 && vw < 4) red[vw * M + m] = ss[v][m];
+                if (lane == 0 && (ALLV || vw < 4)) red[vw * M + m] = ss[v][m];
             }
         }
         __syncthreads();
@@ -286,7 +287,7 @@ __device__ __forceinline__ void gemv_body(const bf16_t* __restrict__ X, const bf
                 for (int i = 0; i < XC; ++i) {
                     const int vw = wave + v * NW;
                     const int c = vw * 64 + lane + i * 256;
-                    if (vw < 4 && c < nxc) {
+                    if ((ALLV || vw < 4) && c < nxc) {
 #pragma unroll
                         for (int m = 0; m < (M <= 4 ? M : 1); ++m) norm_store(c, m, xr[v][i][m], wnr[v][i]);
                     }
