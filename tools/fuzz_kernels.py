@@ -38,6 +38,18 @@ while time.time() - t0 < budget:
     if M <= 128:
         close_bf16(ops.gemm_splitk(a, w, b, r, epi, ri(1, 9)), _epi_ref(acc, b, r, epi))
     n["gemm"] += 1
+    # ---- the phased 256-tile kernel (even number of K-tiles): bit-identical to the others, also when launched repeatedly
+    M, N, K = ri(1, 2600), 8 * ri(1, 400), 128 * ri(2, 40)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    epi, b, r = [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, None, res), (ops.EPI_GELU, bias, None)][ri(0, 2)]
+    want = ops.gemm(a, w, b, r, epi, force="gemm", tile=256)
+    for _ in range(3):
+        got = ops.gemm(a, w, b, r, epi, force="gemm", tile=257)
+        assert torch.equal(got, want), ("phased", M, N, K, epi, int((got != want).sum()))
+    n["gemm_phased"] = n.get("gemm_phased", 0) + 1
     # ---- skinny GEMM / GEMV, 1..32 rows (17..32: two MFMA column blocks)
     M, N, K = ri(1, 32), 16 * ri(1, 300), 32 * ri(1, 64)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)

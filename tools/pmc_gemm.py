@@ -19,8 +19,8 @@ w = torch.empty(N, K, dtype=torch.bfloat16, device=dev).uniform_(-1, 1, generato
 out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr())
-for tile in (256, 128):
+for tile in (257, 256, 128):   # 257: the phased 256-tile kernel (csrc/o3v_gemm8p.hip)
     for rep in range(4):
         _lib.call("o3v_gemm_bf16_tile", P(a), P(w), None, None, P(out), M, N, K, K, K, N // 2, 0, 3, tile, st)
 torch.cuda.synchronize()
-print("done: 4 launches per tile size,", 2.0 * M * N * K / 1e12, "TFLOP each")
+print("done: 4 launches per kernel,", 2.0 * M * N * K / 1e12, "TFLOP each")
