@@ -240,6 +240,11 @@ int o3v_rmsnorm_quantize_fp8(const void* x, const void* w, void* q, float* scale
  * accumulation; epilogue O3V_EPI_NONE / _RESIDUAL / _SWIGLU as o3v_gemm_bf16.  K % 128 == 0, lda / ldw in bytes (= elements). */
 int o3v_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, const void* bias, const void* res, void* out, int M,
                  int N, int K, int lda, int ldw, int ldo, int ldr, int epilogue, o3v_stream_t stream);
+/* o3v_gemm_fp8 with the schedule chosen by the caller (tests, A/B): 0 = the library's choice (the phased kernel wherever K has an even
+ * number >= 4 of 128-byte K-tiles), 1 = the kernel with one __syncthreads() per K-tile, 2 = the phased kernel of csrc/o3v_fp8.hip
+ * (o3v_gemm8p.hip's schedule; O3V_ERR_SHAPE where it does not apply).  Same bits either way. */
+int o3v_gemm_fp8_sched(const void* A8, const float* sa, const void* W8, const float* sw, const void* bias, const void* res, void* out,
+                       int M, int N, int K, int lda, int ldw, int ldo, int ldr, int epilogue, int schedule, o3v_stream_t stream);
 
 /* The PERSISTENT layer block: RMSNorm + q/k/v (+bias, M-RoPE, cache append) -> attention -> merge -> o_proj + residual -> RMSNorm +
  * gate/up + SwiGLU of one decode layer at batch 1 as ONE launch (TF:692-757 up to the SwiGLU; down_proj + residual is the next

@@ -115,6 +115,7 @@ SIGNATURES = {
     "o3v_quantize_rows_fp8": [vp, vp, vp, i32, i32, i32, i32, vp],
     "o3v_rmsnorm_quantize_fp8": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "o3v_gemm_fp8": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "o3v_gemm_fp8_sched": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "o3v_decode_layer_block": [vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                                i32, i32, i32, f32, vp, C.c_uint32, vp],
     "o3v_sample_greedy": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],

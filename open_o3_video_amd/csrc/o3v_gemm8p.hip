@@ -66,11 +66,18 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ A, const b
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) DST[ks][j] =    \
         *reinterpret_cast<const bf16x8*>((SLOT) + swz_off(wn * 32 + j * 16 + fr, ks * 4 + fg))
 // 16 MFMAs: quadrant (row half H, column half JB) over the K-tile, k ascending
+// (the empty asm statements pin the MFMAs -- pure functions of registers -- to their phase: they are ordered against the barriers,
+// and hipcc was seen to sink all MFMAs of the fp8 twin of this loop, o3v_fp8.hip, to the end of the loop body without them)
 #define O3V_MMA(H, JB, BF)                                                                                                          \
+    asm volatile("" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), \
+                 "+v"(af[1][3]), "+v"(BF[0][0]), "+v"(BF[0][1]), "+v"(BF[1][0]), "+v"(BF[1][1]));                                   \
     __builtin_amdgcn_s_setprio(1);                                                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
         acc[H][i][(JB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[H][i][(JB) * 2 + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0)
+    __builtin_amdgcn_s_setprio(0);                                                                                                  \
+    asm volatile("" : "+v"(acc[H][0][(JB) * 2]), "+v"(acc[H][0][(JB) * 2 + 1]), "+v"(acc[H][1][(JB) * 2]),                          \
+                 "+v"(acc[H][1][(JB) * 2 + 1]), "+v"(acc[H][2][(JB) * 2]), "+v"(acc[H][2][(JB) * 2 + 1]),                           \
+                 "+v"(acc[H][3][(JB) * 2]), "+v"(acc[H][3][(JB) * 2 + 1]))
 // issue half-tile (phase + LEAD), wait for all but the 3 youngest, first barrier of the phase
 #define O3V_STAGE_WAIT(P)                                                                                                         \
     {                                                                                                                             \

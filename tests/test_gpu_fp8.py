@@ -130,6 +130,45 @@ def test_gemm_fp8_against_exact_products(need_gpu, M, N, K):
         assert (got == want.to(torch.bfloat16).float()).float().mean() > 0.9
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (1000, 4608, 1024), (77, 1152, 1280), (513, 3584, 3584), (4490, 3584, 18944),
+                                   (2049, 37888, 3584)])
+def test_gemm_fp8_phased_schedule_is_bit_identical(need_gpu, M, N, K):
+    """The phased schedule of the fp8 GEMM (o3v_gemm_fp8_sched schedule 2: 8-MFMA phases between raw barriers, half-tile copies six
+    deep in flight, wave rows one barrier apart) gives the bits of the kernel with one __syncthreads() per K-tile (schedule 1) for
+    every epilogue and at ragged edges, over repeated launches with other traffic in between; the library's own choice (0) is the
+    phased kernel on these shapes; an odd number of K-tiles is refused by schedule 2 and served by schedule 0."""
+    from open_o3_video_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a8 = torch.randint(0, 256, (M, K), generator=g, dtype=torch.uint8)
+    w8 = torch.randint(0, 256, (N, K), generator=g, dtype=torch.uint8)
+    for t in (a8, w8):                       # no NaN encodings (0x7f / 0xff)
+        t[(t & 0x7f) == 0x7f] = 0x3c
+    a8, w8 = a8.cuda(), w8.cuda()
+    sa = torch.exp2(torch.randint(-6, 3, (M,), generator=g).float()).cuda()
+    sw = torch.exp2(torch.randint(-9, -3, (N,), generator=g).float()).cuda()
+    bias = (0.1 * torch.randn(N, generator=g)).to(torch.bfloat16).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    junk = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+
+    def run(sched, epi, b, r, n_out):
+        out = torch.zeros((M, n_out), dtype=torch.bfloat16, device="cuda")
+        rc = _lib.load().o3v_gemm_fp8_sched(_p(a8), _p(sa), _p(w8), _p(sw), _p(b), _p(r), _p(out), M, N, K, K, K, n_out,
+                                            0 if r is None else r.stride(0), epi, sched, _stream())
+        assert rc == 0, rc
+        return out
+    for epi, b, r, n_out in ((0, bias, None, N), (1, None, res, N), (3, None, None, N // 2)):
+        want = run(1, epi, b, r, n_out)
+        for rep in range(4):
+            got = run(2 if rep else 0, epi, b, r, n_out)
+            junk.fill_(rep)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (epi, rep, int((got != want).sum()))
+    o = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    lib = _lib.load()
+    assert lib.o3v_gemm_fp8_sched(_p(a8), _p(sa), _p(w8), _p(sw), None, None, _p(o), M, N, 384, K, K, N, 0, 0, 2, _stream()) == -2
+    assert lib.o3v_gemm_fp8_sched(_p(a8), _p(sa), _p(w8), _p(sw), None, None, _p(o), M, N, 384, K, K, N, 0, 0, 0, _stream()) == 0
+    assert lib.o3v_gemm_fp8_sched(_p(a8), _p(sa), _p(w8), _p(sw), None, None, _p(o), M, N, K, K, K, N, 0, 0, 3, _stream()) == -1
+
+
 def test_gemm_fp8_argument_errors(need_gpu):
     from open_o3_video_amd import _lib
     lib = _lib.load()
