@@ -246,13 +246,15 @@ struct TailNorm {
     float eps = 0.f;
 };
 
-template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8, int CB = 1>
+// RX: 16-row weight blocks per wave for the single-block epilogues (NONE / RESIDUAL / GELU).  At 17..32 rows of x a k-step reads 2 KiB
+// of x fragments (L2) per KiB of weights; two adjacent weight blocks per wave share them (the paired epilogues always did).
+template <int EPI, bool NORM, int KS, bool PACKED, int UT = 8, int CB = 1, int RX = 1>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ norm_w,
                                                         float eps, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
                                                         RopeArgs ra, TailNorm tn) {
-    constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : 1;
+    constexpr int RB = (EPI == EPI_SWIGLU || EPI == EPI_QKVROPE) ? 2 : RX;
     constexpr int RG = 4 / KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NORM: M x (K*2+16)] [KS>1: 4 x RB x 64 x 4 f32] [red]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         rb0[0] = head * ra.D + jb * 16;
         rb0[RB - 1] = rb0[0] + ra.D / 2;
     } else {
-        rb0[0] = grp * 16;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) rb0[b] = (grp * RB + b) * 16;
     }
     const int nks = K >> 5;                      // 32-wide k-steps
     // PACKED: W is the fragment-major image [N/16][K/32][64 lanes][8] (weights.py pack_mfma_fragments): the A fragment
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     s_end = s_end < nks ? s_end : nks;
 
     // ---- epilogue operands of this lane (C[n = rb0 + 4*fg + r][m = fr]): requested now, a kernel's length ahead of their use
-    float e_bias[RB][4], e_res[CB][4], e_cos[CB][4], e_sin[CB][4];
+    float e_bias[RB][4], e_res[EPI == EPI_RESIDUAL ? RB : 1][CB][4], e_cos[CB][4], e_sin[CB][4];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int m = fr + 16 * cb < M ? fr + 16 * cb : 0;
@@ -307,12 +310,11 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
                 int n = rb0[b] + fg * 4 + r;
                 n = n < N ? n : N - 1;
                 e_bias[b][r] = bias ? bf2f(bias[n]) : 0.f;
+                if (EPI == EPI_RESIDUAL) e_res[b][cb][r] = bf2f(res[(size_t)m * ldr + n]);
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int n = rb0[0] + fg * 4 + r;
-            n = n < N ? n : N - 1;
-            e_res[cb][r] = (EPI == EPI_RESIDUAL) ? bf2f(res[(size_t)m * ldr + n]) : 0.f;
+            if (EPI != EPI_RESIDUAL) e_res[0][cb][r] = 0.f;
             if (EPI == EPI_QKVROPE) {
                 const size_t cs = ((size_t)m * ra.cs_stride + ra.cs_off) * ra.D + (rb0[0] < N ? rb0[0] : 0) % ra.D + fg * 4 + r;
                 e_cos[cb][r] = bf2f(ra.cosT[cs]);
@@ -491,18 +493,20 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = rb0[0] + fg * 4 + r;
-            if (n >= N) continue;
-            float v = acc[0][cb][r] + e_bias[0][r];
-            if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[cb][r];
-            if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
-            if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
-            if (EPI == EPI_RESIDUAL && tn.sync)
-                gemv_store_bf16<true>(out + (size_t)m * ldo + n, f2bf(v));  // written through: another XCD's wave normalises the row
-            else
-                out[(size_t)m * ldo + n] = f2bf(v);
-        }
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rb0[b] + fg * 4 + r;
+                if (n >= N) continue;
+                float v = acc[b][cb][r] + e_bias[b][r];
+                if (EPI == EPI_RESIDUAL) v = rbf(v) + e_res[EPI == EPI_RESIDUAL ? b : 0][cb][r];
+                if (EPI == EPI_GELU) v = gelu_erf_f(rbf(v));
+                if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(rbf(v));
+                if (EPI == EPI_RESIDUAL && tn.sync)
+                    gemv_store_bf16<true>(out + (size_t)m * ldo + n, f2bf(v));  // written through: another XCD's wave normalises the row
+                else
+                    out[(size_t)m * ldo + n] = f2bf(v);
+            }
     }
     }
     if constexpr (EPI == EPI_RESIDUAL) {
@@ -1000,6 +1004,13 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     TailNorm tn = a.tn;
     tn.total = grid.x * RG;  // storing waves: one per row group (with a K split the slice-0 wave of each workgroup)
     if (tn.sync && (EPI != EPI_RESIDUAL || tn.total < (uint32_t)M)) return O3V_ERR_SHAPE;
+    // 17..32 rows, single-block epilogues: two adjacent weight blocks per wave (RX = 2) share the x fragments
+    const int groups2 = (a.N + 31) / 32;
+    const dim3 grid2((groups2 + RG - 1) / RG);
+    const size_t shmem2x = KS > 1 ? (size_t)4 * 2 * 2 * 64 * 16 : 0;
+    TailNorm tn2 = a.tn;
+    tn2.total = grid2.x * RG;
+    (void)shmem2x;
 #ifdef O3V_TUNE
 #define O3V_TUNE_UT(U)                                                                                                         \
     if (g_mt_ut == U) {                                                                                                        \
@@ -1019,6 +1030,22 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     O3V_TUNE_UT(4)
     O3V_TUNE_UT(8)
 #undef O3V_TUNE_UT
+    // 100 + U: two weight blocks per wave (RX = 2) at 17..32 rows, U KiB in flight per wave
+#define O3V_TUNE_RX(U)                                                                                                          \
+    if (g_mt_ut == 100 + U) {                                                                                                   \
+        if constexpr (!NORM && RB == 1) {                                                                                       \
+            if (M > 16) {                                                                                                       \
+                O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, U, 2, 2>), grid2, block, shmem2x, a.s, a.X, a.W, a.bias,  \
+                            a.res, a.out, a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn2);                 \
+                return O3V_OK;                                                                                                  \
+            }                                                                                                                   \
+        }                                                                                                                       \
+        return O3V_ERR_SHAPE;                                                                                                   \
+    }
+    O3V_TUNE_RX(16)
+    O3V_TUNE_RX(8)
+    O3V_TUNE_RX(4)
+#undef O3V_TUNE_RX
 #endif
     // 16 KiB of weight loads in flight per wave for the single-block epilogues, 8 KiB for the paired (gate/up, q/k/v) ones:
     // A/B on the 7B shapes in profiles/r01_m8_linear.txt
@@ -1026,6 +1053,14 @@ static int launch_gemv_mfma_p(const GemvArgs& a, int M) {
     if (M > 16) {
         // 17..32 rows: two column blocks per weight fragment (x fragments from L2: no fused norm), half the weight bytes in flight
         // per wave so that the doubled x fragments and accumulators fit the register file
+        if constexpr (!NORM && RB == 1 && KS == 1) {
+            // many row groups and no K split (lm_head): two weight blocks per wave share the x fragments, 4 KiB in flight per wave --
+            // 336.7 -> 237.9 us at 32 rows x 152064 x 3584; with a K split (down_proj, o_proj) the same form is slower, 59 vs 51 us
+            // (profiles/r03_tune_m32.txt)
+            O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, 4, 2, 2>), grid2, block, shmem2x, a.s, a.X, a.W, a.bias, a.res, a.out,
+                        a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn2);
+            return O3V_OK;
+        }
         if constexpr (!NORM) {
             O3V_KLAUNCH((gemv_mfma_kernel<EPI, false, KS, PACKED, 8, 2>), grid, block, shmem2, a.s, a.X, a.W, a.bias, a.res, a.out,
                         a.norm_w, a.eps, M, a.N, a.K, a.ldx, a.ldw, a.ldo, a.ldr, a.ra, tn);

@@ -1477,3 +1477,29 @@ def test_gemm_phased_kernel(dev, M, N, K):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     o = torch.empty(M, N, dtype=BF, device=dev)
     assert _lib.load().o3v_gemm_bf16_phased(P(a), P(w), None, None, P(o), M, N, 192, K, K, N, 0, 0, st) == _lib.ERR_SHAPE
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("M,N,K", [(17, 32784, 256), (24, 40000, 512), (32, 152064, 896), (32, 32768, 3584), (16, 32784, 256)])
+def test_skinny_gemm_many_row_groups(dev, M, N, K, packed):
+    """17..32 rows of x against >= 2048 weight row groups (the lm_head of a 32-video decode step): no K split, and a wave takes TWO
+    adjacent 16-row weight blocks so that they share the x fragments (gemv_mfma_kernel RX = 2).  An odd number of blocks (N = 32784)
+    leaves the last wave one valid block; 16 rows stay on the one-block form.  Row-major and fragment-major weights, every
+    single-block epilogue, against the fp32 reference."""
+    import ctypes as C
+    import kernel_ops as ops
+    from open_o3_video_amd import _lib
+    from open_o3_video_amd.weights import pack_mfma_fragments
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    wp = pack_mfma_fragments(w) if packed else None
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    acc = a.float() @ w.float().t()
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for epi, b, r in [(ops.EPI_NONE, bias, None), (ops.EPI_RESIDUAL, None, res), (ops.EPI_GELU, bias, None)]:
+        out = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+        _lib.call("o3v_linear_decode", P(a), None, 0.0, P(w), P(wp), P(b), P(r), P(out), M, N, K, K, N, N, epi, st)
+        close_bf16(out, _epi_ref(acc, b, r, epi))

@@ -11,11 +11,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "open_o3_video_amd", "csrc")
-OUT = os.path.join(ROOT, "gpurun_out", "libo3v_tune.so")
+OUT = os.path.join(ROOT, "open_o3_video_amd", "libo3v_tune.so")   # in-tree: a built copy travels to the GPU box
 if not os.path.exists(OUT):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-                           "-DO3V_TUNE", "-shared", os.path.join(CSRC, "o3v_gemm.hip"), "-o", OUT])
+                           "-DO3V_TUNE", "-shared", os.path.join(CSRC, "o3v_gemm.hip"), os.path.join(CSRC, "o3v_gemm8p.hip"), "-o", OUT])
 from open_o3_video_amd.weights import pack_mfma_fragments  # noqa: E402
 
 lib = C.CDLL(OUT)
@@ -49,6 +49,8 @@ for name, (N, K, epi, norm) in shapes.items():
     if norm and M > 16:
         continue                      # above 16 rows the linears take no fused norm
     variants = [(0, 0)] + [(ks, ut) for ks in (1, 2, 4) for ut in (4, 8, 16)]   # (0, 0): the library's own choice
+    if M > 16:      # ut = 100 + U: two weight blocks per wave share the x fragments
+        variants += [(ks, 100 + ut) for ks in (1, 2, 4) for ut in (4, 8, 16)]
     variants = [v for v in variants if run(v) == 0]
     res_t = {v: [] for v in variants}
     torch.cuda.synchronize()
