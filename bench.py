@@ -156,9 +156,9 @@ def kernel_roofline(eng, reps=3):
     avg_ms = sorted(per_pass)[len(per_pass) // 2]   # median pass
     bytes_per_launch = 2 * I * H * 2 + H * 2 + I * 2
     ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes per launch from the PMC passes (profiles/r02_gemv_pmc.json; FETCH_SIZE x2 on gfx950)
+    traffic = None  # HBM bytes per launch from the PMC passes (profiles/r03_gemv_pmc.json; FETCH_SIZE x2 on gfx950)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_gemv_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_gemv_pmc.json")) as f:
             pm = json.load(f)
         if pm.get("algorithmic_bytes_per_launch") == bytes_per_launch:
             traffic = pm["hbm_bytes_per_launch"]
@@ -166,7 +166,7 @@ def kernel_roofline(eng, reps=3):
         pass
     return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M=1,R=2,KS=1,SWIGLU,NORM> (RMSNorm + LLM gate/up projection, decode)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": "profiles/r02_gemv_pmc.json (rocprofv3 --pmc passes of this kernel on this shape; "
+            "traffic": traffic, "traffic_source": "profiles/r03_gemv_pmc.json (rocprofv3 --pmc passes of this kernel on this shape; "
                                                   "not a counter of this run)" if traffic is not None else None,
             "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_ms * 1e3, 2)}
 
