@@ -21,7 +21,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
 t0, n = time.time(), {"gemm": 0, "gemv": 0, "fp8_rows": 0, "attn": 0, "prefill_attn": 0}
+t_print = t0
 while time.time() - t0 < budget:
+    if time.time() - t_print > 30:      # a line every half minute: a silent GPU job is taken for hung
+        t_print = time.time()
+        print(f"... {n} after {t_print - t0:.0f} s", flush=True)
     # ---- GEMM (both tilings, launcher's choice included)
     M, N, K = ri(1, 900), 8 * ri(1, 200), 64 * ri(1, 12)
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
