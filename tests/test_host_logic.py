@@ -489,3 +489,51 @@ def test_vllm_video_placeholder_expansion():
     out = llm._tokenize("a<|vision_start|><|video_pad|><|vision_end|>b", 0, 0, [ph3])
     assert "".join(out) == "a" + ph3 + "b"
     assert llm._video_placeholder((2, 4, 4), {"n_frames": 4}) == blk("0.0") + blk("0.1")      # no metadata: fps 24, indices 0..3
+
+
+def test_prompt_identity_key_for_the_generate_to_logps_hand_over():
+    """engine._prompt_key (identity of a prompt between the group generate and the policy's log-prob pass): equal bytes give equal
+    keys; one flipped bit in a pixel, one changed token, another mask, another rope position, another position mode, a reshaped or
+    re-typed visual tensor, a missing tensor all give different keys; lists of frames are keyed by their bytes too."""
+    import types
+    import numpy as np
+    import torch
+    from open_o3_video_amd.engine import O3VEngine
+    me = types.SimpleNamespace(position_mode="pinned")
+    key = lambda ids, mask, pos, tensors, who=me: O3VEngine._prompt_key(who, ids, mask, pos, tensors)
+    g = torch.Generator().manual_seed(3)
+    ids = np.arange(40, dtype=np.int64).reshape(1, 40)
+    mask = np.ones_like(ids)
+    pos = np.stack([ids, ids, ids]).astype(np.int64)
+    pv = torch.randn(96, 1176, generator=g).to(torch.bfloat16)
+    grid = np.asarray([[1, 8, 12]], dtype=np.int64)
+    base = key(ids, mask, pos, (("pv", pv), ("grid", grid), ("frames", None)))
+    assert base == key(ids.copy(), mask.copy(), pos.copy(), (("pv", pv.clone()), ("grid", grid.copy()), ("frames", None)))
+    pv2 = pv.clone()
+    pv2.view(torch.int16)[17, 300] ^= 1
+    ids2 = ids.copy()
+    ids2[0, -1] += 1
+    mask2 = mask.copy()
+    mask2[0, 0] = 0
+    pos2 = pos.copy()
+    pos2[1, 0, 5] += 1
+    others = [key(ids, mask, pos, (("pv", pv2), ("grid", grid), ("frames", None))),
+              key(ids2, mask, pos, (("pv", pv), ("grid", grid), ("frames", None))),
+              key(ids, mask2, pos, (("pv", pv), ("grid", grid), ("frames", None))),
+              key(ids, mask, pos2, (("pv", pv), ("grid", grid), ("frames", None))),
+              key(ids, mask, pos, (("pv", pv), ("grid", grid), ("frames", None)), types.SimpleNamespace(position_mode="tf5")),
+              key(ids, mask, pos, (("pv", pv.view(48, 2352)), ("grid", grid), ("frames", None))),
+              key(ids, mask, pos, (("pv", pv.view(torch.int16)), ("grid", grid), ("frames", None))),
+              key(ids, mask, pos, (("pv", None), ("grid", grid), ("frames", None))),
+              key(ids, mask, pos, (("pv", pv), ("grid", np.asarray([[1, 12, 8]], dtype=np.int64)), ("frames", None)))]
+    assert all(o != base for o in others) and len(set(others)) == len(others)
+    # two rows swapped keep the plain sum and change the position-weighted one
+    pv3 = pv.clone()
+    pv3[[0, 1]] = pv3[[1, 0]]
+    assert key(ids, mask, pos, (("pv", pv3), ("grid", grid), ("frames", None))) != base
+    fr = [torch.randint(0, 256, (3, 28, 28), generator=g, dtype=torch.uint8) for _ in range(3)]
+    k1 = key(ids, mask, pos, (("frames", fr),))
+    fr2 = [f.clone() for f in fr]
+    assert k1 == key(ids, mask, pos, (("frames", fr2),))
+    fr2[2][1, 5, 5] ^= 4
+    assert k1 != key(ids, mask, pos, (("frames", fr2),))
